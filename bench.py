@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Benchmark of the Relation-DETR hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--queries 900] [--batch 4]
+
+Workload (BASELINE.json configs[1]): relation_detr_resnet50_800_1333 -- padded image 800x1344, 4-level
+pyramid (100,168)(50,84)(25,42)(13,21), S = 22,323 tokens, 8 heads x 32 channels, 4 points,
+batch 4 per GPU, N_q decoder queries (900 = what the reference config runs; 300 via --queries 300).
+One step = one pass of the hot path over one batch of synthetic, HBM-resident inputs:
+    6 x encoder MultiScaleDeformableAttention (N_q = S)            [module: 4 dense projections + HIP core]
+    6 x decoder layer hot ops: RelationSelfAttention (bias + softmax HIP kernel) and
+        MultiScaleDeformableAttention cross-attention (N_q queries)
+    5 x PositionRelationEmbedding (HIP relation-bias kernel)
+(backbone, FFN/LayerNorm and heads are outside the path and not in the step -- stated in
+config.workload).  Random-init weights, synthetic inputs ("data": "synthetic").
+
+Multi-GPU: images are independent, so ranks take disjoint image blocks (weak scaling, batch 4 per
+GPU) with no data-path collective; the only exchange is the eval all-gather of the [B,300,6]
+detections over RCCL, done once per step.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel =
+encoder MSDA gather; algorithmic bytes from BASELINE.md section 4 / SURVEY.md section 8d) and
+`cpu_baseline` (the oracle's op-for-op PyTorch restatement on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R50_SHAPES = [(100, 168), (50, 84), (25, 42), (13, 21)]
+HBM_PEAK = 8.0e12           # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def msda_algorithmic_bytes(B, S, Nq, L, P, H, D, value_bytes):
+    """value read once (or only touched rows) + loc + weights + output."""
+    touched = min(S * H * D, Nq * H * L * P * 4 * D)
+    return B * (touched * value_bytes + Nq * H * L * P * 2 * 4 + Nq * H * L * P * 4 + Nq * H * D * value_bytes)
+
+
+def build_inputs(B, Nq, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = torch.tensor(R50_SHAPES, dtype=torch.int64)
+    areas = shapes[:, 0] * shapes[:, 1]
+    start = torch.cat([areas.new_zeros(1), areas.cumsum(0)[:-1]])
+    S = int(areas.sum())
+    L = len(R50_SHAPES)
+    # encoder reference points = pixel centres of every level, broadcast over levels (base_transformer.py:57-75)
+    refs = []
+    for h, w in R50_SHAPES:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    enc_ref = torch.cat(refs, 0)[None, :, None, :].expand(B, S, L, 2).contiguous()
+    dec_ref = torch.cat([torch.rand(B, Nq, 2, generator=g) * 0.8 + 0.1, torch.rand(B, Nq, 2, generator=g) * 0.48 + 0.02], -1)
+    inp = dict(
+        shapes=shapes.to(dev), start=start.to(dev), S=S, L=L,
+        memory=torch.randn(B, S, 256, generator=g).to(dev),
+        pos=torch.randn(B, S, 256, generator=g).to(dev),
+        enc_ref=enc_ref.to(dev),
+        query=torch.randn(B, Nq, 256, generator=g).to(dev),
+        query_pos=torch.randn(B, Nq, 256, generator=g).to(dev),
+        dec_ref=dec_ref[:, :, None, :].expand(B, Nq, L, 4).contiguous().to(dev),
+        boxes=[torch.cat([torch.rand(B, Nq, 2, generator=g), torch.rand(B, Nq, 2, generator=g) * 0.49 + 0.01], -1).to(dev)
+               for _ in range(6)],
+    )
+    return inp
+
+
+def randomise(mod, g):
+    """Fresh MSDA modules have zero offset/attention weights (uniform weights, fixed ring offsets);
+    give them trained-like spread so the gather pattern is data dependent."""
+    with torch.no_grad():
+        mod.sampling_offsets.weight.copy_(torch.randn(mod.sampling_offsets.weight.shape, generator=g) * 0.02)
+        mod.attention_weights.weight.copy_(torch.randn(mod.attention_weights.weight.shape, generator=g) * 0.05)
+    return mod
+
+
+class HotPath(torch.nn.Module):
+    def __init__(self, seed=0):
+        super().__init__()
+        import relation_detr_amd as rd
+        g = torch.Generator().manual_seed(seed)
+        self.enc_attn = torch.nn.ModuleList(randomise(rd.MultiScaleDeformableAttention(256, 4, 8, 4), g) for _ in range(6))
+        self.dec_self = torch.nn.ModuleList(rd.RelationSelfAttention(256, 8) for _ in range(6))
+        self.dec_cross = torch.nn.ModuleList(randomise(rd.MultiScaleDeformableAttention(256, 4, 8, 4), g) for _ in range(6))
+        self.relation = rd.PositionRelationEmbedding(16, 8)
+
+    @torch.no_grad()
+    def forward(self, x):
+        mem = x["memory"]
+        for layer in self.enc_attn:                       # relation_transformer.py:262-269
+            mem = layer(query=mem + x["pos"], reference_points=x["enc_ref"], value=mem, spatial_shapes=x["shapes"],
+                        level_start_index=x["start"], key_padding_mask=None)
+        q = x["query"]
+        rel = None
+        for i in range(6):                                # relation_transformer.py:452-471, 369-374
+            qp = q + x["query_pos"]
+            q = self.dec_self[i](query=qp, key=qp, value=q, attn_mask=rel, need_weights=False)[0]
+            q = self.dec_cross[i](query=q + x["query_pos"], reference_points=x["dec_ref"], value=mem,
+                                  spatial_shapes=x["shapes"], level_start_index=x["start"], key_padding_mask=None)
+            if i < 5:
+                rel = self.relation(x["boxes"][i], x["boxes"][i + 1]).flatten(0, 1)
+        return q
+
+
+def time_encoder_kernel(x, B, dtype, reps=20):
+    """Average duration of the dominant kernel (encoder-shape MSDA gather) from device events on the
+    launch stream, with pixel-centre + N(0, (k/W)^2) offsets."""
+    import relation_detr_amd as rd
+    dev = x["memory"].device
+    S, L = x["S"], x["L"]
+    g = torch.Generator().manual_seed(123)
+    value = torch.randn(B, S, 8, 32, generator=g).to(dev).to(dtype)
+    wh = x["shapes"].flip(-1).float().cpu()
+    k = torch.arange(1, 5, dtype=torch.float32).view(1, 1, 1, 1, 4, 1)
+    off = torch.randn(B, S, 8, L, 4, 2, generator=g) * k / wh.view(1, 1, 1, L, 1, 2)
+    loc = (x["enc_ref"].cpu()[:, :, None, :, None, :] + off).contiguous().to(dev)
+    attn = torch.softmax(torch.randn(B, S, 8, L * 4, generator=g), -1).view(B, S, 8, L, 4).contiguous().to(dev)
+    for _ in range(3):
+        rd.ms_deform_attn_forward(value, x["shapes"], x["start"], loc, attn, 64)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        rd.ms_deform_attn_forward(value, x["shapes"], x["start"], loc, attn, 64)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def cpu_baseline(Nq, budget_s=25.0):
+    """The oracle's op-for-op PyTorch restatement of the same step on the host cores, ONE image
+    (B=1), repeated until ~budget_s of CPU work; returns images/s."""
+    from oracle import torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = build_inputs(1, Nq, "cpu", 7)
+    g = torch.Generator().manual_seed(0)
+    import relation_detr_amd as rd
+    net = HotPath(0)
+    sd = {k: v for k, v in net.state_dict().items()}
+
+    def msda(prefix, query, ref, value):
+        params = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        return torch_ref.msda_module_forward(params, query, ref, value, x["shapes"], x["start"], None)
+
+    def one_image():
+        with torch.no_grad():
+            mem = x["memory"]
+            for i in range(6):
+                mem = msda(f"enc_attn.{i}.", mem + x["pos"], x["enc_ref"], mem)
+            q, rel = x["query"], None
+            for i in range(6):
+                qp = q + x["query_pos"]
+                p = f"dec_self.{i}."
+                q = torch_ref.self_attn_with_bias(qp, qp, q, sd[p + "in_proj_weight"], sd[p + "in_proj_bias"],
+                                                  sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], rel)
+                q = msda(f"dec_cross.{i}.", q + x["query_pos"], x["dec_ref"], mem)
+                if i < 5:
+                    rel = torch_ref.relation_bias(x["boxes"][i], x["boxes"][i + 1], sd["relation.pos_proj.0.weight"],
+                                                  sd["relation.pos_proj.0.bias"]).flatten(0, 1)
+            return q
+
+    one_image()                                             # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one_image()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 16:
+            break
+    return {"value": n / el, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x 1 image (B=1) of the same step, torch {torch.__version__} CPU kernels, fp32, "
+                      f"{cores} threads, oracle/torch_ref.py (per-level grid_sample + stack + weighted sum)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--queries", type=int, default=900)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from relation_detr_amd import _lib
+    from relation_detr_amd.dist import gather_detections
+    _lib.load()
+
+    B, Nq = args.batch, args.queries
+    x = build_inputs(B, Nq, dev, seed=1000 + rank)          # each rank owns its own image block
+    net = HotPath(0).to(dev).eval()
+    amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16")
+    dets = torch.rand(B, 300, 6, device=dev)                # stand-in [x1,y1,x2,y2,score,label] per image
+    img_ids = torch.arange(B, device=dev) + rank * B
+
+    def step():
+        with amp:
+            out = net(x)
+        if world > 1:
+            gather_detections(dets, img_ids)                # eval path: one RCCL all-gather per step
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+
+    kdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    t_kernel = time_encoder_kernel(x, B, kdtype)
+    alg = msda_algorithmic_bytes(B, x["S"], x["S"], x["L"], 4, 8, 32, 2 if args.dtype == "bf16" else 4)
+
+    if rank == 0:
+        res = {
+            "metric": "images/sec @ 800x1333, R50 4-level; achieved HBM GB/s",
+            "value": world * B * args.steps / el, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"relation_detr_resnet50_800_1333 hot path: 6x encoder MSDA module (S=22323) + "
+                                   f"6x decoder [self-attn with relation bias + MSDA cross-attn] + 5x relation "
+                                   f"embedding; backbone/FFN/LayerNorm/heads excluded",
+                       "batch_per_gpu": B, "global_batch": B * world, "queries": Nq, "levels": 4,
+                       "parallelism": f"image-parallel x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "msda_fwd_wave_kernel (encoder shape, B=%d)" % B,
+                         "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": alg / t_kernel / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(Nq)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/*
+ * relation_detr_amd.h -- C ABI of librelation_detr_amd.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the Relation-DETR hot path.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch tensor.data_ptr()) unless marked host;
+ *   - tensors are contiguous, row-major; the caller allocates every output;
+ *   - the library never allocates, never synchronises and keeps no global state: a call only
+ *     enqueues kernels on `stream` (a hipStream_t passed as void*; NULL = the default stream),
+ *     so calls are re-entrant across streams and capturable in a hipGraph;
+ *   - return value: RDETR_OK (0) or a negative rdetr_status; rdetr_status_string() explains it.
+ *     Unlike the reference (kernel-launch errors are printf'd and ignored,
+ *     models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:937-941) launch errors are returned.
+ */
+#ifndef RELATION_DETR_AMD_H
+#define RELATION_DETR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDETR_ABI_VERSION 1
+
+typedef enum rdetr_status {
+    RDETR_OK = 0,
+    RDETR_ERR_INVALID_ARG = -1,   /* null pointer, negative size, misaligned pointer */
+    RDETR_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for */
+    RDETR_ERR_LAUNCH = -3         /* hipGetLastError() != hipSuccess after the launch */
+} rdetr_status;
+
+int rdetr_abi_version(void);
+const char *rdetr_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, forward.
+ * Replaces  _C.ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc,
+ *           attn_weight, im2col_step)            models/bricks/ops/cuda/ms_deform_attn_cuda.cu:12-72,148-150
+ *           (kernel ms_deformable_im2col_gpu_kernel, ms_deform_im2col_cuda.cuh:226-288) and equals
+ *           multi_scale_deformable_attn_pytorch  models/bricks/ms_deform_attn.py:159-212.
+ *
+ *   value          [B, S, H, D]        levels packed along S, row-major (y*W_l + x) inside a level
+ *   spatial_shapes [L, 2] int64 (h,w)  level_start_index [L] int64          (device memory)
+ *   sampling_loc   [B, Nq, H, L, P, 2] fp32, (x, y) normalised to [0,1]
+ *   attn_weight    [B, Nq, H, L, P]    fp32 (already soft-maxed over L*P by the caller)
+ *   out            [B, Nq, H*D]        channel = head*D + c
+ *
+ * Fast path: H*D*sizeof(T) a multiple of 16 bytes, D in {32} and H <= 8 ... see rdetr_msda_fast_path();
+ * any other (H, D) runs a generic one-thread-per-output kernel.  There is no im2col_step batch
+ * restriction (the reference requires B % min(B, 64) == 0, ms_deform_attn_cuda.cu:42-44).
+ * NaN sampling locations contribute zero (the CUDA op's guard, ms_deform_im2col_cuda.cuh:277).
+ * The bf16 variant stores value and out as bfloat16 and keeps locations, weights and the
+ * accumulation in fp32 (an extension: the reference op is fp32/fp64 only, ms_deform_attn_cuda.cu:56).
+ */
+int rdetr_msda_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                           const float *sampling_loc, const float *attn_weight, int B, int S, int H, int D,
+                           int L, int Nq, int P, float *out, void *stream);
+
+int rdetr_msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                            const float *sampling_loc, const float *attn_weight, int B, int S, int H, int D,
+                            int L, int Nq, int P, uint16_t *out, void *stream);
+
+/* 1 if (H, D, L, P) is served by the wave-per-query kernel, 0 if by the generic kernel. */
+int rdetr_msda_fast_path(int H, int D, int L, int P);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, backward.
+ * Replaces  _C.ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc,
+ *           attn_weight, grad_output, im2col_step) -> [grad_value, grad_sampling_loc, grad_attn_weight]
+ *           models/bricks/ops/cuda/ms_deform_attn_cuda.cu:75-145, ms_deform_im2col_cuda.cuh:290-392.
+ * grad_value [B,S,H,D] is accumulated with float atomics and MUST be zero-filled by the caller
+ * (the reference zero-fills inside the op, ms_deform_attn_cuda.cu:113-115; the Python wrapper does
+ * it here).  grad_sampling_loc / grad_attn_weight are fully overwritten.
+ */
+int rdetr_msda_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                            const float *sampling_loc, const float *attn_weight, const float *grad_out, int B,
+                            int S, int H, int D, int L, int Nq, int P, float *grad_value,
+                            float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Position-relation bias.
+ * Replaces  PositionRelationEmbedding.forward  models/bricks/relation_transformer.py:520-532
+ *           = box_rel_encoding (:481-490) -> get_sine_pos_embed (models/bricks/position_encoding.py:115-138)
+ *             -> Conv2d(4*F -> Hh, 1x1) + ReLU -> clone.
+ *   src [B, N1, 4], tgt [B, N2, 4]   cxcywh boxes, fp32
+ *   proj_weight [Hh, 4*F]  (pos_proj.0.weight flattened), proj_bias [Hh] (may be NULL)
+ *   out [B, Hh, N1, N2]    fp32, >= 0;  rows = src (queries), cols = tgt (keys)
+ * F = num_pos_feats (16 in every relation_detr config), must be even and <= 32; Hh <= 16.
+ */
+int rdetr_relation_bias_f32(const float *src, const float *tgt, const float *proj_weight, const float *proj_bias,
+                            int B, int N1, int N2, int Hh, int F, float scale, float temperature, float eps,
+                            float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bias-add + row softmax of decoder self-attention scores, in place.
+ * Replaces the softmax(QK^T/sqrt(d) + attn_mask) step of nn.MultiheadAttention as called at
+ * models/bricks/relation_transformer.py:452-459 (float mask [B*Hh, N, N] from :372-374).
+ *   scores [BH, N1, N2] fp32, overwritten with the probabilities
+ *   bias   [BH, N1, N2] fp32 or NULL (may contain -inf)
+ *   mask   [N1, N2] uint8 or NULL; non-zero = excluded (the bool attn_mask convention)
+ * A fully masked row yields NaN, as torch.softmax does.
+ */
+int rdetr_bias_softmax_f32(float *scores, const float *bias, const uint8_t *mask, int BH, int N1, int N2,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELATION_DETR_AMD_H */

@@ -1,0 +1,58 @@
+"""ctypes binding of librelation_detr_amd.so (the C ABI declared in include/relation_detr_amd.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing the ops
+raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C relation_detr_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librelation_detr_amd.so")
+
+_c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (restype is int unless noted); mirrors include/relation_detr_amd.h one to one.
+SIGNATURES = {
+    "rdetr_abi_version": [],
+    "rdetr_status_string": [_c_int],
+    "rdetr_msda_fast_path": [_c_int] * 4,
+    "rdetr_msda_forward_f32": [_vp] * 5 + [_c_int] * 7 + [_vp, _vp],
+    "rdetr_msda_forward_bf16": [_vp] * 5 + [_c_int] * 7 + [_vp, _vp],
+    "rdetr_msda_backward_f32": [_vp] * 6 + [_c_int] * 7 + [_vp] * 4,
+    "rdetr_relation_bias_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp],
+    "rdetr_bias_softmax_f32": [_vp] * 3 + [_c_int] * 3 + [_vp],
+}
+
+_lib = None
+
+
+class RdetrError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RdetrError(
+            f"{LIB_PATH} not found: the HIP kernels are not built. Run `make -C relation_detr_amd/csrc` "
+            "(needs hipcc, --offload-arch=gfx950). There is no CPU or PyTorch fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "rdetr_status_string" else _c_int
+    if lib.rdetr_abi_version() != 1:
+        raise RdetrError(f"ABI version mismatch: library {lib.rdetr_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().rdetr_status_string(status).decode()
+        raise RdetrError(f"{what} failed: {msg} (status {status})")

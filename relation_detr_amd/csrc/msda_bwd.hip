@@ -1,0 +1,232 @@
+// Multi-scale deformable attention, backward (fp32) -- hand-written for gfx950 (MI355X).
+//
+// Replaces ms_deformable_col2im_cuda and, for head_dim 32, its kernel
+// ms_deformable_col2im_gpu_kernel_shm_blocksize_aware_reduce_v1<T,32>
+// (models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:290-392,1129-1150: block = 32 threads = one
+// (b,q,head), 4 atomicAdd per thread per point, thread 0 serially sums 32 partials for the
+// location / weight gradients).
+//
+// Same wave-per-query decomposition as the forward kernel (msda_fwd.hip): lane = head*8 + sub owns
+// 4 channels.  Per point the lane re-gathers the 4 corners (needed for d/dloc and d/dweight),
+// scatters w_corner * g * attn into grad_value with hardware fp32 atomics (each wave instruction
+// adds eight 128-byte head rows; out-of-level corners carry offset 0x80000000 and are dropped by
+// the buffer range check), and the per-head sums over D = 32 channels for grad_loc / grad_attn
+// are an 8-lane xor-shuffle reduction instead of a shared-memory pass.
+//
+// Float atomics make grad_value's summation order run-dependent (as in the reference).
+#include "common.h"
+
+namespace rdetr {
+
+constexpr int kBH = 8, kBD = 32, kBP = 4, kBMaxL = 8, kBWaves = 4;
+constexpr unsigned kBInvalid = 0x80000000u;
+constexpr unsigned kBPixelBytes = kBH * kBD * 4, kBHeadBytes = kBD * 4;
+
+struct BwdLevels {
+    int h[kBMaxL], w[kBMaxL], start[kBMaxL];
+};
+
+__device__ __forceinline__ float sum8(float v)
+{
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+__device__ __forceinline__ void atomic_add4(__amdgpu_buffer_rsrc_t rs, unsigned off, f32x4 v)
+{
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.x, rs, off, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.y, rs, off + 4, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.z, rs, off + 8, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.w, rs, off + 12, 0, 0);
+}
+
+__global__ __launch_bounds__(kBWaves *kWave) void msda_bwd_wave_kernel(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc, const float *__restrict__ attn, const float *__restrict__ grad_out, int S, int L,
+    int Nq, int tiles_per_image, int nblk, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_attn)
+{
+    const int LP = L * kBP;
+    __shared__ BwdLevels lvl;
+    // per wave, [point][head]: corner offsets | {hy, hx, ly, lx} | {attn, W_l, H_l, inside}
+    __shared__ u32x4 st_off[kBWaves][kBMaxL * kBP * kBH];
+    __shared__ f32x4 st_frac[kBWaves][kBMaxL * kBP * kBH];
+    __shared__ f32x4 st_misc[kBWaves][kBMaxL * kBP * kBH];
+
+    const int tid = threadIdx.x;
+    if (tid < L) {
+        lvl.h[tid] = (int)shapes[2 * tid];
+        lvl.w[tid] = (int)shapes[2 * tid + 1];
+        lvl.start[tid] = (int)level_start[tid];
+    }
+    __syncthreads();
+
+    const int logical = xcd_contiguous_block(blockIdx.x, nblk);
+    const int b = logical / tiles_per_image;
+    const int tile = logical - b * tiles_per_image;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, m = lane >> 3, sub = lane & 7;
+    const int q = tile * kBWaves + wave;
+    if (q >= Nq) return;
+
+    const size_t img = (size_t)b * S * (kBH * kBD);
+    const __amdgpu_buffer_rsrc_t rs_v =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value) + img, 0, (unsigned)S * kBPixelBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g =
+        __builtin_amdgcn_make_buffer_rsrc(grad_value + img, 0, (unsigned)S * kBPixelBytes, 0x00020000);
+    const unsigned lane_off = (unsigned)m * kBHeadBytes + (unsigned)sub * 16u;
+
+    const size_t row = (size_t)b * Nq + q;
+    const size_t hrow = (row * kBH + m) * (size_t)LP;
+    u32x4 *soff = st_off[wave];
+    f32x4 *sfrac = st_frac[wave];
+    f32x4 *smisc = st_misc[wave];
+
+    for (int pt = sub; pt < LP; pt += 8) {
+        const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + (hrow + pt) * 2);
+        const float a = attn[hrow + pt];
+        const int l = pt / kBP;
+        const int h = lvl.h[l], w = lvl.w[l];
+        const float x = xy.x * (float)w - 0.5f, y = xy.y * (float)h - 0.5f;
+        const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = inside ? (int)xf : 0, y0 = inside ? (int)yf : 0;
+        const float lx = inside ? x - xf : 0.f, ly = inside ? y - yf : 0.f;   // NaN-safe
+        const bool okx0 = inside && x0 >= 0, okx1 = inside && x0 + 1 <= w - 1;
+        const bool oky0 = y0 >= 0, oky1 = y0 + 1 <= h - 1;
+        const unsigned base = (unsigned)(lvl.start[l] + y0 * w + x0) * kBPixelBytes;
+        const unsigned rowb = (unsigned)w * kBPixelBytes;
+        u32x4 o;
+        o.x = (okx0 && oky0) ? base : kBInvalid;
+        o.y = (okx1 && oky0) ? base + kBPixelBytes : kBInvalid;
+        o.z = (okx0 && oky1) ? base + rowb : kBInvalid;
+        o.w = (okx1 && oky1) ? base + rowb + kBPixelBytes : kBInvalid;
+        soff[pt * kBH + m] = o;
+        sfrac[pt * kBH + m] = f32x4{1.f - ly, 1.f - lx, ly, lx};
+        smisc[pt * kBH + m] = f32x4{inside ? a : 0.f, (float)w, (float)h, inside ? 1.f : 0.f};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const f32x4 g = reinterpret_cast<const f32x4 *>(grad_out + row * (kBH * kBD))[lane];
+
+#pragma unroll 2
+    for (int pt = 0; pt < LP; ++pt) {
+        const u32x4 o = soff[pt * kBH + m];
+        const f32x4 fr = sfrac[pt * kBH + m];       // hy, hx, ly, lx
+        const f32x4 mi = smisc[pt * kBH + m];       // attn (0 if outside), W, H, inside
+        const f32x4 v00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.x + lane_off, 0, 0));
+        const f32x4 v01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.y + lane_off, 0, 0));
+        const f32x4 v10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.z + lane_off, 0, 0));
+        const f32x4 v11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.w + lane_off, 0, 0));
+        const float hy = fr.x, hx = fr.y, ly = fr.z, lx = fr.w;
+        const f32x4 ga = g * mi.x;                                   // top_grad * attn_weight
+        atomic_add4(rs_g, o.x + lane_off, (hy * hx) * ga);
+        atomic_add4(rs_g, o.y + lane_off, (hy * lx) * ga);
+        atomic_add4(rs_g, o.z + lane_off, (ly * hx) * ga);
+        atomic_add4(rs_g, o.w + lane_off, (ly * lx) * ga);
+        // d/dx and d/dy of the bilinear sample (ms_deform_im2col_cuda.cuh:102-141)
+        const f32x4 dxs = hy * (v01 - v00) + ly * (v11 - v10);
+        const f32x4 dys = hx * (v10 - v00) + lx * (v11 - v01);
+        const f32x4 smp = (hy * hx) * v00 + (hy * lx) * v01 + (ly * hx) * v10 + (ly * lx) * v11;
+        const float ga_w = sum8(dot4(g, smp)) * mi.w;                // grad wrt attention weight
+        const float gx = sum8(dot4(ga, dxs)) * mi.y;                 // * W_l
+        const float gy = sum8(dot4(ga, dys)) * mi.z;                 // * H_l
+        if (sub == (pt & 7)) {
+            grad_attn[hrow + pt] = ga_w;
+            *reinterpret_cast<f32x2 *>(grad_loc + (hrow + pt) * 2) = f32x2{gx, gy};
+        }
+    }
+}
+
+// Generic fallback: one thread per (b, q, head, point), loops over D; any (H, D, L, P).
+__global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc, const float *__restrict__ attn, const float *__restrict__ grad_out, int S, int H,
+    int D, int L, int Nq, int P, long long total, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_attn)
+{
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total;
+         k += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)((k / P) % L);
+        const long long r = k / ((long long)L * P);          // (b*Nq + q)*H + m
+        const int m = (int)(r % H);
+        const long long bq = r / H;
+        const long long b = bq / Nq;
+        const long long pix = (long long)H * D;
+        const int h = (int)shapes[2 * l], w = (int)shapes[2 * l + 1];
+        const float x = loc[2 * k] * (float)w - 0.5f, y = loc[2 * k + 1] * (float)h - 0.5f;
+        float g_a = 0.f, g_x = 0.f, g_y = 0.f;
+        if ((y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w)) {
+            const float a = attn[k];
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+            const bool k00 = y0 >= 0 && x0 >= 0, k01 = y0 >= 0 && x0 + 1 <= w - 1;
+            const bool k10 = y0 + 1 <= h - 1 && x0 >= 0, k11 = y0 + 1 <= h - 1 && x0 + 1 <= w - 1;
+            const long long o00 = b * S * pix + (level_start[l] + (long long)y0 * w + x0) * pix + (long long)m * D;
+            const long long o01 = o00 + pix, o10 = o00 + (long long)w * pix, o11 = o10 + pix;
+            const float *go = grad_out + bq * pix + (long long)m * D;
+            for (int c = 0; c < D; ++c) {
+                const float gc = go[c], ga = gc * a;
+                const float v00 = k00 ? value[o00 + c] : 0.f, v01 = k01 ? value[o01 + c] : 0.f;
+                const float v10 = k10 ? value[o10 + c] : 0.f, v11 = k11 ? value[o11 + c] : 0.f;
+                if (k00) atomicAdd(grad_value + o00 + c, hy * hx * ga);
+                if (k01) atomicAdd(grad_value + o01 + c, hy * lx * ga);
+                if (k10) atomicAdd(grad_value + o10 + c, ly * hx * ga);
+                if (k11) atomicAdd(grad_value + o11 + c, ly * lx * ga);
+                g_a += gc * (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11);
+                g_x += ga * (hy * (v01 - v00) + ly * (v11 - v10));
+                g_y += ga * (hx * (v10 - v00) + lx * (v11 - v01));
+            }
+            g_x *= (float)w;
+            g_y *= (float)h;
+        }
+        grad_attn[k] = g_a;
+        grad_loc[2 * k] = g_x;
+        grad_loc[2 * k + 1] = g_y;
+    }
+}
+
+}  // namespace rdetr
+
+using namespace rdetr;
+
+extern "C" int rdetr_msda_backward_f32(const float *value, const int64_t *spatial_shapes,
+                                       const int64_t *level_start_index, const float *sampling_loc,
+                                       const float *attn_weight, const float *grad_out, int B, int S, int H, int D,
+                                       int L, int Nq, int P, float *grad_value, float *grad_sampling_loc,
+                                       float *grad_attn_weight, void *stream)
+{
+    if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
+    if (B == 0 || Nq == 0) return RDETR_OK;
+    if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_out || !grad_value ||
+        !grad_sampling_loc || !grad_attn_weight || S == 0)
+        return RDETR_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    const bool fast = H == kBH && D == kBD && P == kBP && L <= kBMaxL && al16(value) && al16(grad_out) &&
+                      al16(grad_value) && reinterpret_cast<uintptr_t>(sampling_loc) % 8 == 0 &&
+                      reinterpret_cast<uintptr_t>(grad_sampling_loc) % 8 == 0 &&
+                      (long long)S * kBPixelBytes < (1ll << 31);
+    if (fast) {
+        const int tiles = (Nq + kBWaves - 1) / kBWaves;
+        const long long nblk = (long long)B * tiles;
+        if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(msda_bwd_wave_kernel, dim3((unsigned)nblk), dim3(kBWaves * kWave), 0, st, value,
+                           spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, S, L, Nq, tiles,
+                           (int)nblk, grad_value, grad_sampling_loc, grad_attn_weight);
+        return launch_status();
+    }
+    const long long total = (long long)B * Nq * H * L * P;
+    const long long want = (total + 255) / 256;
+    hipLaunchKernelGGL(msda_bwd_generic_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, st, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, S, H, D, L, Nq, P, total,
+                       grad_value, grad_sampling_loc, grad_attn_weight);
+    return launch_status();
+}

@@ -1,0 +1,105 @@
+"""Drop-in ``MultiScaleDeformableAttention`` backed by the gfx950 HIP kernels.
+
+API contract taken from the reference module (models/bricks/ms_deform_attn.py:215-377): same
+constructor ``(embed_dim, num_levels, num_heads, num_points, img2col_step)``, same attributes
+(``im2col_step, embed_dim, num_heads, num_levels, num_points``), same sub-module names -- hence the
+same state_dict keys ``sampling_offsets / attention_weights / value_proj / output_proj`` (the
+optimiser grouping matches on ``sampling_offsets``, optimizer/param_dict.py:82) -- same
+``init_weights()`` and the same keyword ``forward``.  The four projections stay ``nn.Linear``
+(rocBLAS / hipBLASLt, i.e. MFMA); the gather-and-weighted-sum core is ``rdetr_msda_forward_*``.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+
+
+def sampling_locations(reference_points: Tensor, offsets: Tensor, spatial_shapes: Tensor, num_points: int) -> Tensor:
+    """reference_points [B,Nq,L,2|4], offsets [B,Nq,H,L,P,2] -> normalised (x, y) locations
+    [B,Nq,H,L,P,2]  (ms_deform_attn.py:339-349)."""
+    last = reference_points.shape[-1]
+    if last == 2:
+        wh = spatial_shapes.flip(-1).to(offsets.dtype)                          # (w, h) per level
+        return reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+    if last == 4:
+        centre = reference_points[:, :, None, :, None, :2]
+        size = reference_points[:, :, None, :, None, 2:]
+        return centre + offsets / num_points * size * 0.5
+    raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(last))
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    def __init__(self, embed_dim: int = 256, num_levels: int = 4, num_heads: int = 8, num_points: int = 4,
+                 img2col_step: int = 64):
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise ValueError(
+                "embed_dim must be divisible by num_heads, but got {} and {}".format(embed_dim, num_heads))
+        head_dim = embed_dim // num_heads
+        if head_dim & (head_dim - 1):
+            warnings.warn("head_dim is not a power of two; the wave-per-query HIP kernel needs head_dim == 32, "
+                          "other sizes run the generic kernel")
+        self.im2col_step = img2col_step            # accepted for compatibility; the HIP op has no batch chunking
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.num_levels = num_levels
+        self.num_points = num_points
+        self.sampling_offsets = nn.Linear(embed_dim, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dim, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dim, embed_dim)
+        self.output_proj = nn.Linear(embed_dim, embed_dim)
+        self.init_weights()
+
+    def init_weights(self):
+        """Reference initialisation (ms_deform_attn.py:266-284): zero offset weights with a ring of
+        unit directions per head scaled by the point index as bias, uniform attention, xavier projections."""
+        nn.init.zeros_(self.sampling_offsets.weight)
+        angle = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        ring = torch.stack([angle.cos(), angle.sin()], -1)
+        ring = ring / ring.abs().max(-1, keepdim=True)[0]
+        ring = ring.view(self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        ring = ring * torch.arange(1, self.num_points + 1, dtype=torch.float32).view(1, 1, self.num_points, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(ring.reshape(-1))
+        nn.init.zeros_(self.attention_weights.weight)
+        nn.init.zeros_(self.attention_weights.bias)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.zeros_(self.value_proj.bias)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.zeros_(self.output_proj.bias)
+
+    def project_inputs(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
+                       key_padding_mask):
+        """Everything before the core: value projection (+ padding zero-fill), offsets, soft-maxed
+        weights, sampling locations.  Pure torch (dense GEMMs + elementwise), device-agnostic."""
+        B, Nq, _ = query.shape
+        S = value.shape[1]
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        v = self.value_proj(value)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], float(0))
+        v = v.view(B, S, H, self.embed_dim // H)
+        offsets = self.sampling_offsets(query).view(B, Nq, H, L, P, 2)
+        weights = self.attention_weights(query).view(B, Nq, H, L * P).softmax(-1).view(B, Nq, H, L, P)
+        return v, sampling_locations(reference_points, offsets, spatial_shapes, P), weights
+
+    def forward(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
+                level_start_index: Tensor, key_padding_mask: Tensor) -> Tensor:
+        """query [B,Nq,C]; reference_points [B,Nq,L,2] or [B,Nq,L,4]; value [B,S,C]; spatial_shapes
+        [L,2] (h,w); level_start_index [L]; key_padding_mask [B,S] bool or None -> [B,Nq,C]."""
+        if value.is_cuda:      # same consistency check as the reference (:313), from a cached host copy
+            shapes, _ = ops.host_levels(spatial_shapes, level_start_index)
+            assert sum(h * w for h, w in shapes) == value.shape[1]
+        v, loc, weights = self.project_inputs(query, reference_points, value, spatial_shapes, key_padding_mask)
+        core_dtype = v.dtype if v.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        core = ops.MultiScaleDeformableAttnFunction.apply(
+            v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, loc.float().contiguous(),
+            weights.float().contiguous(), self.im2col_step)
+        if core.dtype != v.dtype:
+            core = core.to(v.dtype)
+        return self.output_proj(core)

@@ -1,0 +1,193 @@
+"""Operator layer: torch tensors in, HIP kernels (through the C ABI) out.
+
+Mirrors the reference's pybind module ``_C`` (models/bricks/ops/cuda/ms_deform_attn_cuda.cu:148-151):
+``ms_deform_attn_forward`` / ``ms_deform_attn_backward`` keep the reference's argument order and
+meaning, allocate and return new tensors, require contiguous device tensors and run on the current
+stream.  ``relation_bias`` and ``bias_softmax_`` are the two relation-path operators.
+
+No CPU path: a tensor that is not on a ROCm device raises, and so does a missing library.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_device(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.RdetrError(
+                "relation_detr_amd operators need tensors on a ROCm device (got a CPU tensor); "
+                "there is no CPU fallback on the product path")
+
+
+def _require_contiguous(**named: torch.Tensor) -> None:
+    for name, t in named.items():
+        if t is not None and not t.is_contiguous():
+            raise _lib.RdetrError(f"{name} tensor has to be contiguous")      # AT_ASSERTM, ms_deform_attn_cuda.cu:20-24
+
+
+# host copies of (spatial_shapes, level_start_index) keyed by storage identity: one D2H sync per new
+# pyramid instead of one per call (the reference syncs on every call, ms_deform_attn.py:313).
+_shape_cache: dict = {}
+
+
+def host_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor) -> Tuple[tuple, tuple]:
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, level_start_index.data_ptr(),
+           level_start_index._version, str(spatial_shapes.device), tuple(spatial_shapes.shape))
+    hit = _shape_cache.get(key)
+    if hit is None:
+        if len(_shape_cache) > 64:
+            _shape_cache.clear()
+        hit = (tuple(map(tuple, spatial_shapes.tolist())), tuple(level_start_index.tolist()))
+        _shape_cache[key] = hit
+    return hit
+
+
+def check_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, num_value: int) -> None:
+    """Host-side validation that the pyramid description matches the value tensor, so that the
+    kernel's indexing assumptions hold before anything is launched."""
+    if spatial_shapes.dim() != 2 or spatial_shapes.shape[1] != 2 or spatial_shapes.dtype != torch.int64:
+        raise _lib.RdetrError("spatial_shapes must be an int64 tensor of shape [L, 2]")
+    if level_start_index.dtype != torch.int64 or level_start_index.numel() != spatial_shapes.shape[0]:
+        raise _lib.RdetrError("level_start_index must be an int64 tensor of shape [L]")
+    shapes, starts = host_levels(spatial_shapes, level_start_index)
+    for (h, w), s in zip(shapes, starts):
+        if h <= 0 or w <= 0 or s < 0 or s + h * w > num_value:
+            raise _lib.RdetrError(
+                f"level (h={h}, w={w}, start={s}) does not fit a value tensor with {num_value} positions")
+
+
+def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
+                           sampling_loc: torch.Tensor, attn_weight: torch.Tensor, im2col_step: int = 64) -> torch.Tensor:
+    """value [B,S,H,D] (fp32 or bf16), sampling_loc [B,Nq,H,L,P,2] fp32, attn_weight [B,Nq,H,L,P] fp32
+    -> [B,Nq,H*D] in value's dtype.  ``im2col_step`` is accepted and ignored (no batch restriction)."""
+    _require_device(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                        sampling_loc=sampling_loc, attn_weight=attn_weight)
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise _lib.RdetrError("expected value [B,S,H,D], sampling_loc [B,Nq,H,L,P,2], attn_weight [B,Nq,H,L,P]")
+    B, S, H, D = value.shape
+    _, Nq, H2, L, P, two = sampling_loc.shape
+    if (H2, two) != (H, 2) or tuple(attn_weight.shape) != (B, Nq, H, L, P) or sampling_loc.shape[0] != B:
+        raise _lib.RdetrError("sampling_loc / attn_weight shapes do not match value")
+    if spatial_shapes.shape[0] != L:
+        raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_loc")
+    if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
+        raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
+    check_levels(spatial_shapes, level_start_index, S)
+    lib = _lib.load()
+    out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if value.dtype == torch.float32:
+        fn = lib.rdetr_msda_forward_f32
+    elif value.dtype == torch.bfloat16:
+        fn = lib.rdetr_msda_forward_bf16
+    else:
+        raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
+    st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
+    _lib.check(st, "rdetr_msda_forward")
+    return out
+
+
+def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
+                            sampling_loc: torch.Tensor, attn_weight: torch.Tensor, grad_output: torch.Tensor,
+                            im2col_step: int = 64):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (fp32), as ms_deform_attn_cuda.cu:75-145."""
+    _require_device(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
+    grad_output = grad_output.contiguous()
+    _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                        sampling_loc=sampling_loc, attn_weight=attn_weight)
+    if value.dtype != torch.float32 or grad_output.dtype != torch.float32:
+        raise _lib.RdetrError("ms_deform_attn_backward is float32 only")
+    B, S, H, D = value.shape
+    _, Nq, _, L, P, _ = sampling_loc.shape
+    if tuple(grad_output.shape) != (B, Nq, H * D):
+        raise _lib.RdetrError("grad_output must be [B, Nq, H*D]")
+    check_levels(spatial_shapes, level_start_index, S)
+    grad_value = torch.zeros_like(value)                       # accumulated with atomics
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    st = _lib.load().rdetr_msda_backward_f32(
+        value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+        attn_weight.data_ptr(), grad_output.data_ptr(), B, S, H, D, L, Nq, P, grad_value.data_ptr(),
+        grad_loc.data_ptr(), grad_attn.data_ptr(), _stream_ptr(value))
+    _lib.check(st, "rdetr_msda_backward_f32")
+    return [grad_value, grad_loc, grad_attn]
+
+
+class MultiScaleDeformableAttnFunction(torch.autograd.Function):
+    """Autograd wrapper with the reference's signature (models/bricks/ms_deform_attn.py:35-84)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step=64):
+        ctx.im2col_step = im2col_step
+        out = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                     attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, attn = ctx.saved_tensors
+        gv, gl, ga = ms_deform_attn_backward(value.float(), shapes, starts, loc, attn, grad_output.float(),
+                                             ctx.im2col_step)
+        return gv.to(value.dtype), None, None, gl, ga, None
+
+
+def relation_bias(src_boxes: torch.Tensor, tgt_boxes: torch.Tensor, proj_weight: torch.Tensor,
+                  proj_bias: Optional[torch.Tensor], num_pos_feats: int = 16, temperature: float = 10000.0,
+                  scale: float = 100.0, eps: float = 1e-5) -> torch.Tensor:
+    """boxes [B,N,4] cxcywh, proj_weight [Hh, 4F(,1,1)], proj_bias [Hh] -> ReLU(conv1x1(sine(rel))) [B,Hh,N1,N2]."""
+    _require_device(src_boxes, tgt_boxes, proj_weight, proj_bias)
+    if src_boxes.dim() != 3 or tgt_boxes.dim() != 3 or src_boxes.shape[0] != tgt_boxes.shape[0]:
+        raise _lib.RdetrError("boxes must be [B, N, 4] with equal batch size")
+    src = src_boxes.detach().float().contiguous()
+    tgt = tgt_boxes.detach().float().contiguous()
+    Hh = proj_weight.shape[0]
+    w = proj_weight.detach().float().reshape(Hh, -1).contiguous()
+    if w.shape[1] != 4 * num_pos_feats:
+        raise _lib.RdetrError(f"proj_weight has {w.shape[1]} input channels, expected {4 * num_pos_feats}")
+    b = None if proj_bias is None else proj_bias.detach().float().contiguous()
+    B, N1, _ = src.shape
+    N2 = tgt.shape[1]
+    out = torch.empty(B, Hh, N1, N2, dtype=torch.float32, device=src.device)
+    st = _lib.load().rdetr_relation_bias_f32(src.data_ptr(), tgt.data_ptr(), w.data_ptr(),
+                                             None if b is None else b.data_ptr(), B, N1, N2, Hh, num_pos_feats,
+                                             scale, temperature, eps, out.data_ptr(), _stream_ptr(src))
+    _lib.check(st, "rdetr_relation_bias_f32")
+    return out
+
+
+def bias_softmax_(scores: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """In place: scores[BH,N1,N2] <- softmax(scores + bias, -1); mask [N1,N2] bool, True = excluded."""
+    _require_device(scores, bias, mask)
+    if scores.dtype != torch.float32 or scores.dim() != 3:
+        raise _lib.RdetrError("scores must be a float32 [BH, N1, N2] tensor")
+    _require_contiguous(scores=scores)
+    BH, N1, N2 = scores.shape
+    if bias is not None:
+        if bias.dtype != torch.float32 or tuple(bias.shape) != (BH, N1, N2):
+            raise _lib.RdetrError("bias must be float32 with the shape of scores")
+        bias = bias.contiguous()
+    mask_u8 = None
+    if mask is not None:
+        if tuple(mask.shape) != (N1, N2):
+            raise _lib.RdetrError("mask must be [N1, N2]")
+        mask_u8 = mask.to(torch.uint8).contiguous()
+    st = _lib.load().rdetr_bias_softmax_f32(scores.data_ptr(), None if bias is None else bias.data_ptr(),
+                                            None if mask_u8 is None else mask_u8.data_ptr(), BH, N1, N2,
+                                            _stream_ptr(scores))
+    _lib.check(st, "rdetr_bias_softmax_f32")
+    return scores

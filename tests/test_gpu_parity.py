@@ -1,0 +1,319 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): HIP kernels, called through the C ABI via
+relation_detr_amd.ops / the nn.Modules, against (1) the committed golden vectors produced by the
+reference itself and (2) the CPU oracle on seeded inputs.
+
+Tolerances (north_star: <= 1e-4 abs fp32 vs the pure-PyTorch fallback):
+  fp32 MSDA forward / module / relation bias / self-attention   atol 1e-4
+  bf16 MSDA forward: |err| <= 2^-8 * |ref| + 1e-3  vs the fp32 oracle on bf16-rounded value (one
+       output rounding to bf16, fp32 accumulation) -- an extension, the reference op has no bf16.
+  backward: grad_value / grad_attn atol 1e-4; grad_loc rtol 1e-4 + atol 5e-4 away from interpolation
+       kinks (helpers.kink_mask) -- it is scaled by W_l/H_l and sums 32 channels.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import kink_mask, make_msda_inputs, pyramid
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def rd():
+    import relation_detr_amd
+    from relation_detr_amd import _lib
+    _lib.load()                      # fail loudly if the HIP library is missing
+    return relation_detr_amd
+
+
+def _core(rd, value, shapes, start, loc, attn):
+    out = rd.ms_deform_attn_forward(value.to(DEV).contiguous(), shapes.to(DEV), start.to(DEV),
+                                    loc.to(DEV).contiguous(), attn.to(DEV).contiguous(), 64)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+# ------------------------------------------------------------------------------------------ MSDA forward
+@pytest.mark.parametrize("name", ["g1_msda_core.npz", "g3_msda_core_l5.npz"])
+def test_msda_forward_golden(rd, golden, name):
+    g = golden(name)
+    out = _core(rd, T(g["value"]), T(g["shapes"]), T(g["level_start"]), T(g["loc"]), T(g["attn"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=1e-4)
+    if "out_f64" in g:
+        np.testing.assert_allclose(out.numpy(), g["out_f64"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("shapes,B,Nq", [
+    ([(25, 42), (13, 21), (7, 11), (4, 6)], 3, 257),          # L=4 fast path, ragged Nq (not a multiple of 16)
+    ([(19, 31), (10, 16), (5, 8), (3, 4), (2, 2)], 2, 130),   # L=5 fast path
+    ([(9, 14), (5, 7)], 2, 65),                               # run-time L path
+    ([(6, 6)], 1, 1),                                         # single level, single query
+])
+def test_msda_forward_vs_oracle(rd, shapes, B, Nq):
+    from oracle import c_oracle, torch_ref
+    value, shp, start, loc, attn = make_msda_inputs(B, Nq, shapes, seed=11)
+    out = _core(rd, value, shp, start, loc, attn).numpy()
+    ref_c = c_oracle.msda_forward(value.numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
+    ref_t = torch_ref.msda_core(value, shp, loc, attn).numpy()
+    np.testing.assert_allclose(out, ref_c, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out, ref_t, rtol=0, atol=1e-4)
+
+
+def test_msda_forward_generic_shapes(rd):
+    """(H, D, P) outside the wave-per-query kernel run the generic kernel."""
+    from oracle import c_oracle
+    for H, D, P in [(4, 16, 2), (8, 32, 3), (2, 64, 4)]:
+        assert rd._lib.load().rdetr_msda_fast_path(H, D, 3, P) == 0
+        value, shp, start, loc, attn = make_msda_inputs(2, 33, [(8, 12), (4, 6), (2, 3)], H=H, D=D, P=P, seed=5)
+        out = _core(rd, value, shp, start, loc, attn).numpy()
+        ref = c_oracle.msda_forward(value.numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)
+
+
+def test_msda_forward_bf16(rd):
+    from oracle import c_oracle
+    value, shp, start, loc, attn = make_msda_inputs(2, 300, [(25, 42), (13, 21), (7, 11), (4, 6)], seed=3)
+    vb = value.to(torch.bfloat16)
+    out = _core(rd, vb, shp, start, loc, attn)
+    assert out.dtype == torch.bfloat16
+    ref = c_oracle.msda_forward(vb.float().numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
+    err = np.abs(out.float().numpy() - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-3).all(), err.max()
+
+
+def test_msda_forward_nan_and_far_locations(rd):
+    """NaN / huge locations contribute zero (CUDA-op guard) and never fault."""
+    value, shp, start, loc, attn = make_msda_inputs(1, 16, [(8, 12), (4, 6), (2, 3), (1, 2)], seed=9)
+    loc2 = loc.clone()
+    loc2[0, 0] = float("nan")
+    loc2[0, 1] = 1e30
+    loc2[0, 2] = -1e30
+    loc2[0, 3] = float("inf")
+    out = _core(rd, value, shp, start, loc2, attn)
+    assert torch.isfinite(out).all()
+    assert (out[0, :4] == 0).all()
+    ref = _core(rd, value, shp, start, loc, attn)
+    assert torch.equal(out[0, 4:], ref[0, 4:])
+
+
+def test_msda_empty_and_errors(rd):
+    value, shp, start, loc, attn = make_msda_inputs(1, 4, [(4, 4)], seed=1)
+    out = rd.ms_deform_attn_forward(value.to(DEV), shp.to(DEV), start.to(DEV), loc[:, :0].to(DEV).contiguous(),
+                                    attn[:, :0].to(DEV).contiguous(), 64)
+    assert out.shape == (1, 0, 256)
+    with pytest.raises(RuntimeError):                               # CPU tensors: no fallback
+        rd.ms_deform_attn_forward(value, shp, start, loc, attn, 64)
+    with pytest.raises(RuntimeError):                               # non-contiguous, as AT_ASSERTM in the reference
+        rd.ms_deform_attn_forward(value.to(DEV).transpose(2, 3), shp.to(DEV), start.to(DEV), loc.to(DEV),
+                                  attn.to(DEV), 64)
+    bad = shp.clone()
+    bad[0, 0] = 99                                                  # level does not fit S: refused on the host
+    with pytest.raises(RuntimeError):
+        rd.ms_deform_attn_forward(value.to(DEV), bad.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV), 64)
+
+
+# ------------------------------------------------------------------------------------------ MSDA backward
+def test_msda_backward_golden(rd, golden):
+    g, gb = golden("g1_msda_core.npz"), golden("g2_msda_core_bwd.npz")
+    args = [T(g[k]).to(DEV) for k in ("value", "shapes", "level_start", "loc", "attn")]
+    gv, gl, ga = rd.ms_deform_attn_backward(*args, T(gb["grad_out"]).to(DEV), 64)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(gv.cpu().numpy(), gb["grad_value"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ga.cpu().numpy(), gb["grad_attn"], rtol=0, atol=1e-4)
+    ok = kink_mask(g["loc"], g["shapes"])
+    np.testing.assert_allclose(np.where(ok, gl.cpu().numpy(), 0), np.where(ok, gb["grad_loc"], 0), rtol=1e-4, atol=5e-4)
+
+
+def test_msda_autograd_vs_oracle(rd):
+    from oracle import c_oracle
+    value, shp, start, loc, attn = make_msda_inputs(2, 70, [(12, 18), (6, 9), (3, 5), (2, 3)], seed=21)
+    go = torch.randn(2, 70, 256, generator=torch.Generator().manual_seed(2))
+    v, l, a = (t.to(DEV).requires_grad_() for t in (value, loc, attn))
+    out = rd.MultiScaleDeformableAttnFunction.apply(v, shp.to(DEV), start.to(DEV), l, a, 64)
+    out.backward(go.to(DEV))
+    gv, gl, ga = c_oracle.msda_backward(value.numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy(), go.numpy())
+    np.testing.assert_allclose(v.grad.cpu().numpy(), gv, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), ga, rtol=0, atol=1e-4)
+    ok = kink_mask(loc.numpy(), shp.numpy())
+    np.testing.assert_allclose(np.where(ok, l.grad.cpu().numpy(), 0), np.where(ok, gl, 0), rtol=1e-4, atol=5e-4)
+
+
+def test_msda_backward_generic_shapes(rd):
+    from oracle import c_oracle
+    value, shp, start, loc, attn = make_msda_inputs(2, 21, [(8, 12), (4, 6)], H=4, D=16, P=2, seed=8)
+    go = torch.randn(2, 21, 64, generator=torch.Generator().manual_seed(4))
+    gv, gl, ga = rd.ms_deform_attn_backward(value.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV),
+                                            go.to(DEV), 64)
+    rv, rl, ra = c_oracle.msda_backward(value.numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy(), go.numpy())
+    np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ga.cpu().numpy(), ra, rtol=0, atol=1e-4)
+    ok = kink_mask(loc.numpy(), shp.numpy())
+    np.testing.assert_allclose(np.where(ok, gl.cpu().numpy(), 0), np.where(ok, rl, 0), rtol=1e-4, atol=5e-4)
+
+
+# ------------------------------------------------------------------------------------------ module
+def test_msda_module_golden(rd, golden):
+    g = golden("g4_msda_module.npz")
+    mod = rd.MultiScaleDeformableAttention(256, 4, 8, 4)
+    mod.load_state_dict({k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")})
+    mod = mod.to(DEV).eval()
+    shapes, start = T(g["shapes"]).to(DEV), T(g["level_start"]).to(DEV)
+    with torch.no_grad():
+        enc = mod(query=T(g["q_enc"]).to(DEV), reference_points=T(g["ref2"]).to(DEV), value=T(g["feat"]).to(DEV),
+                  spatial_shapes=shapes, level_start_index=start, key_padding_mask=T(g["mask"]).to(DEV))
+        dec = mod(query=T(g["q_dec"]).to(DEV), reference_points=T(g["ref4"]).to(DEV), value=T(g["feat"]).to(DEV),
+                  spatial_shapes=shapes, level_start_index=start, key_padding_mask=None)
+    np.testing.assert_allclose(enc.cpu().numpy(), g["out_enc"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(dec.cpu().numpy(), g["out_dec"], rtol=0, atol=1e-4)
+
+
+def test_msda_module_bf16_autocast(rd, golden):
+    g = golden("g4_msda_module.npz")
+    mod = rd.MultiScaleDeformableAttention(256, 4, 8, 4)
+    mod.load_state_dict({k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")})
+    mod = mod.to(DEV).eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        dec = mod(query=T(g["q_dec"]).to(DEV), reference_points=T(g["ref4"]).to(DEV), value=T(g["feat"]).to(DEV),
+                  spatial_shapes=T(g["shapes"]).to(DEV), level_start_index=T(g["level_start"]).to(DEV),
+                  key_padding_mask=None)
+    assert dec.dtype == torch.bfloat16
+    # bf16 GEMMs dominate the error here; this only checks that the bf16 kernel path is wired correctly
+    np.testing.assert_allclose(dec.float().cpu().numpy(), g["out_dec"], rtol=0, atol=6e-2)
+
+
+# ------------------------------------------------------------------------------------------ relation bias
+def test_relation_bias_golden(rd, golden):
+    g = golden("g5_relation.npz")
+    rel = rd.PositionRelationEmbedding(16, 8)
+    rel.load_state_dict({"pos_proj.0.weight": T(g["proj_weight"]), "pos_proj.0.bias": T(g["proj_bias"])})
+    rel = rel.to(DEV).eval()
+    with torch.no_grad():
+        bias = rel(T(g["src"]).to(DEV), T(g["tgt"]).to(DEV))
+        bias_self = rel(T(g["src"]).to(DEV))
+        bias_tiny = rel(T(g["tiny_src"]).to(DEV), T(g["tiny_tgt"]).to(DEV))
+    assert bias.shape == (2, 8, 23, 31)
+    np.testing.assert_allclose(bias.cpu().numpy(), g["bias"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(bias.cpu().numpy(), g["bias_f64"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(bias_self.cpu().numpy(), g["bias_self"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(bias_tiny.cpu().numpy(), g["bias_tiny"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(bias_tiny.cpu().numpy(), g["bias_tiny_f64"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,N1,N2", [(1, 300, 300), (2, 129, 67), (1, 1, 1), (3, 5, 900)])
+def test_relation_bias_vs_oracle(rd, B, N1, N2):
+    from oracle import torch_ref
+    g = torch.Generator().manual_seed(N1 * 7 + N2)
+    src = torch.cat([torch.rand(B, N1, 2, generator=g), torch.rand(B, N1, 2, generator=g) * 0.49 + 0.01], -1)
+    tgt = torch.cat([torch.rand(B, N2, 2, generator=g), torch.rand(B, N2, 2, generator=g) * 0.49 + 0.01], -1)
+    w = (torch.rand(8, 64, 1, 1, generator=g) - 0.5) * 0.25
+    b = (torch.rand(8, generator=g) - 0.5) * 0.25
+    out = rd.relation_bias(src.to(DEV), tgt.to(DEV), w.to(DEV), b.to(DEV))
+    ref64 = torch_ref.relation_bias(src.double(), tgt.double(), w.double(), b.double()).float()
+    ref32 = torch_ref.relation_bias(src, tgt, w, b)
+    np.testing.assert_allclose(out.cpu().numpy(), ref32.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), ref64.numpy(), rtol=0, atol=1e-4)
+
+
+def test_relation_bias_generic_heads(rd):
+    from oracle import torch_ref
+    g = torch.Generator().manual_seed(77)
+    src = torch.cat([torch.rand(2, 40, 2, generator=g), torch.rand(2, 40, 2, generator=g) * 0.4 + 0.02], -1)
+    w = (torch.rand(4, 32, 1, 1, generator=g) - 0.5) * 0.3            # Hh = 4, F = 8
+    b = (torch.rand(4, generator=g) - 0.5) * 0.3
+    out = rd.relation_bias(src.to(DEV), src.to(DEV), w.to(DEV), b.to(DEV), num_pos_feats=8)
+    ref = torch_ref.relation_bias(src, src, w, b, num_pos_feats=8)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+
+
+def test_relation_bias_weight_grad(rd):
+    from oracle import torch_ref
+    g = torch.Generator().manual_seed(5)
+    src = torch.cat([torch.rand(2, 33, 2, generator=g), torch.rand(2, 33, 2, generator=g) * 0.4 + 0.02], -1)
+    tgt = torch.cat([torch.rand(2, 29, 2, generator=g), torch.rand(2, 29, 2, generator=g) * 0.4 + 0.02], -1)
+    rel = rd.PositionRelationEmbedding(16, 8).to(DEV)
+    go = torch.randn(2, 8, 33, 29, generator=g)
+    rel(src.to(DEV), tgt.to(DEV)).backward(go.to(DEV))
+    w = rel.pos_proj[0].weight.detach().cpu().clone().requires_grad_()
+    b = rel.pos_proj[0].bias.detach().cpu().clone().requires_grad_()
+    torch_ref.relation_bias(src, tgt, w, b).backward(go)
+    np.testing.assert_allclose(rel.pos_proj[0].weight.grad.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(rel.pos_proj[0].bias.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------ bias softmax / self-attention
+@pytest.mark.parametrize("BH,N1,N2", [(8, 50, 50), (16, 300, 300), (8, 37, 901), (2, 5, 1100), (1, 3, 5000), (4, 900, 900)])
+def test_bias_softmax_vs_torch(rd, BH, N1, N2):
+    g = torch.Generator().manual_seed(BH + N2)
+    s = torch.randn(BH, N1, N2, generator=g) * 4
+    b = torch.rand(BH, N1, N2, generator=g) * 3
+    m = torch.rand(N1, N2, generator=g) < 0.2
+    m[:, 0] = False
+    for bias, mask in ((b, None), (None, None), (b, m), (None, m)):
+        ref = s if bias is None else s + bias
+        if mask is not None:
+            ref = ref.masked_fill(mask, float("-inf"))
+        ref = torch.softmax(ref, -1)
+        out = rd.bias_softmax_(s.clone().to(DEV), None if bias is None else bias.to(DEV),
+                               None if mask is None else mask.to(DEV))
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)
+
+
+def test_bias_softmax_inf_bias_rows(rd):
+    s = torch.randn(2, 4, 64)
+    b = torch.zeros(2, 4, 64)
+    b[:, :, 10:] = float("-inf")
+    out = rd.bias_softmax_(s.clone().to(DEV), b.to(DEV)).cpu()
+    np.testing.assert_allclose(out.numpy(), torch.softmax(s + b, -1).numpy(), rtol=0, atol=2e-6)
+    assert (out[..., 10:] == 0).all()
+
+
+def test_self_attention_golden(rd, golden):
+    g = golden("g6_self_attn.npz")
+    att = rd.RelationSelfAttention(256, 8)
+    att.load_state_dict({"in_proj_weight": T(g["in_proj_weight"]), "in_proj_bias": T(g["in_proj_bias"]),
+                         "out_proj.weight": T(g["out_proj_weight"]), "out_proj.bias": T(g["out_proj_bias"])})
+    att = att.to(DEV).eval()
+    qp, vv = T(g["qp"]).to(DEV), T(g["vv"]).to(DEV)
+    rb, bm = T(g["rel_bias"]).to(DEV), T(g["bool_mask"]).to(DEV)
+    cases = {"out_bias": rb, "out_none": None, "out_bool": bm, "out_bias_inf": rb.masked_fill(bm, float("-inf"))}
+    with torch.no_grad():
+        for key, mask in cases.items():
+            out = att(query=qp, key=qp, value=vv, attn_mask=mask, need_weights=False)[0]
+            np.testing.assert_allclose(out.cpu().numpy(), g[key], rtol=0, atol=1e-4, err_msg=key)
+
+
+# ------------------------------------------------------------------------------------------ full-size checks
+R50 = [(100, 168), (50, 84), (25, 42), (13, 21)]
+
+
+def test_full_size_encoder_vs_oracle(rd):
+    """BASELINE.json config 1/2 encoder shape (S = Nq = 22,323) against the torch oracle on the host."""
+    from oracle import torch_ref
+    value, shp, start, loc, attn = make_msda_inputs(1, 22323, R50, seed=0, spread=0.02)
+    out = _core(rd, value, shp, start, loc, attn)
+    ref = torch_ref.msda_core(value, shp, loc, attn)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=1e-4)
+
+
+def test_full_size_properties(rd):
+    """Size-independent properties at B=4 (BASELINE.json config 2): linearity in value, and a constant
+    value map sampled strictly inside every level returns that constant (weights sum to one)."""
+    shp, start, S = pyramid(R50)
+    g = torch.Generator().manual_seed(1)
+    B, Nq = 4, 22323
+    v1 = torch.randn(B, S, 8, 32, generator=g).to(DEV)
+    v2 = torch.randn(B, S, 8, 32, generator=g).to(DEV)
+    wh = shp.flip(-1).float()
+    loc = (torch.rand(B, Nq, 8, 4, 4, 2, generator=g) * (1 - 2.0 / wh.view(1, 1, 1, 4, 1, 2)) + 1.0 / wh.view(1, 1, 1, 4, 1, 2)).to(DEV)
+    attn = torch.softmax(torch.randn(B, Nq, 8, 16, generator=g), -1).view(B, Nq, 8, 4, 4).to(DEV)
+    shp_d, start_d = shp.to(DEV), start.to(DEV)
+    o1 = rd.ms_deform_attn_forward(v1, shp_d, start_d, loc, attn, 64)
+    o2 = rd.ms_deform_attn_forward(v2, shp_d, start_d, loc, attn, 64)
+    o12 = rd.ms_deform_attn_forward(v1 + 0.5 * v2, shp_d, start_d, loc, attn, 64)
+    assert (o12 - (o1 + 0.5 * o2)).abs().max().item() < 2e-5
+    const = torch.arange(256, dtype=torch.float32, device=DEV).view(1, 1, 8, 32).expand(B, S, 8, 32).contiguous() / 64
+    oc = rd.ms_deform_attn_forward(const, shp_d, start_d, loc, attn, 64)
+    assert (oc - const[:, :1].reshape(B, 1, 256)).abs().max().item() < 2e-5

@@ -1,0 +1,133 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the nn.Modules keep the reference's constructor / attribute / state_dict contract, the
+pre-kernel torch logic (sampling locations) matches the oracle, and the product path refuses to run
+without a device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import relation_detr_amd as rd
+from relation_detr_amd import _lib, ops
+from oracle import torch_ref
+
+T = torch.from_numpy
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "relation_detr_amd.h")).read()
+    declared = set(re.findall(r"\b(rdetr_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().rdetr_abi_version() == 1
+    assert _lib.load().rdetr_status_string(-2).decode().startswith("shape not supported")
+    assert _lib.load().rdetr_msda_fast_path(8, 32, 4, 4) == 1
+    assert _lib.load().rdetr_msda_fast_path(8, 32, 5, 4) == 1
+    assert _lib.load().rdetr_msda_fast_path(8, 64, 4, 4) == 0
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Argument checks run before any HIP call, so they are testable on a CPU-only host."""
+    lib = _lib.load()
+    assert lib.rdetr_msda_forward_f32(None, None, None, None, None, 1, 10, 8, 32, 4, 5, 4, None, None) == -1
+    assert lib.rdetr_msda_forward_f32(None, None, None, None, None, 0, 10, 8, 32, 4, 5, 4, None, None) == 0   # empty batch
+    assert lib.rdetr_msda_forward_f32(None, None, None, None, None, 1, 10, 8, 32, 4, -1, 4, None, None) == -1
+    assert lib.rdetr_relation_bias_f32(None, None, None, None, 1, 4, 4, 8, 15, 100.0, 10000.0, 1e-5, None, None) == -2  # odd F
+    assert lib.rdetr_relation_bias_f32(None, None, None, None, 1, 4, 4, 8, 16, 100.0, 10000.0, 1e-5, None, None) == -1
+    assert lib.rdetr_bias_softmax_f32(None, None, None, 0, 4, 4, None) == 0
+    assert lib.rdetr_bias_softmax_f32(None, None, None, 2, 4, 4, None) == -1
+    assert lib.rdetr_msda_backward_f32(*([None] * 6), 1, 10, 8, 32, 4, 5, 4, None, None, None, None) == -1
+
+
+def test_msda_module_contract(golden):
+    g = golden("g4_msda_module.npz")
+    mod = rd.MultiScaleDeformableAttention(256, 4, 8, 4)              # positional, as relation_transformer.py:223,401
+    assert (mod.im2col_step, mod.embed_dim, mod.num_heads, mod.num_levels, mod.num_points) == (64, 256, 8, 4, 4)
+    ref_sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    assert {k: tuple(v.shape) for k, v in mod.state_dict().items()} == {k: v.shape for k, v in ref_sd.items()}
+    # fresh-module initialisation equals the reference's: the offset bias ring pattern was NOT randomised
+    # in the fixture, zero offset weights / uniform attention are the reference's documented init
+    np.testing.assert_allclose(mod.sampling_offsets.bias.detach().numpy(), ref_sd["sampling_offsets.bias"], atol=1e-6)
+    assert mod.sampling_offsets.weight.abs().max() == 0 and mod.attention_weights.weight.abs().max() == 0
+    assert mod.attention_weights.bias.abs().max() == 0 and mod.value_proj.bias.abs().max() == 0
+    mod.load_state_dict({k: T(v) for k, v in ref_sd.items()})          # released checkpoints load
+    with pytest.raises(ValueError):
+        rd.MultiScaleDeformableAttention(250, 4, 8, 4)
+
+
+def test_msda_module_pre_kernel_logic_matches_oracle(golden):
+    g = golden("g4_msda_module.npz")
+    mod = rd.MultiScaleDeformableAttention(256, 4, 8, 4)
+    mod.load_state_dict({k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")})
+    shapes = T(g["shapes"])
+    with torch.no_grad():
+        for q, ref, mask in ((T(g["q_enc"]), T(g["ref2"]), T(g["mask"])), (T(g["q_dec"]), T(g["ref4"]), None)):
+            v, loc, w = mod.project_inputs(q, ref, T(g["feat"]), shapes, mask)
+            off = mod.sampling_offsets(q).view(*q.shape[:2], 8, 4, 4, 2)
+            np.testing.assert_allclose(loc.numpy(), torch_ref.sampling_locations_from_reference(ref, off, shapes, 4).numpy(), atol=1e-6)
+            assert v.shape == (2, 321, 8, 32) and w.shape == (*q.shape[:2], 8, 4, 4)
+            np.testing.assert_allclose(w.sum((-1, -2)).numpy(), 1.0, atol=1e-5)
+            if mask is not None:
+                assert v[mask].abs().max() == 0
+            # the core of the product path is HIP-only: on CPU tensors it refuses instead of falling back
+            with pytest.raises(_lib.RdetrError):
+                mod(query=q, reference_points=ref, value=T(g["feat"]), spatial_shapes=shapes,
+                    level_start_index=T(g["level_start"]), key_padding_mask=mask)
+    with pytest.raises(ValueError):
+        rd.ms_deform_attn.sampling_locations(torch.zeros(1, 2, 4, 3), torch.zeros(1, 2, 8, 4, 4, 2), shapes, 4)
+
+
+def test_relation_module_contract(golden):
+    g = golden("g5_relation.npz")
+    rel = rd.PositionRelationEmbedding(16, 8)
+    assert rd.PositionRelationEncoder is rd.PositionRelationEmbedding
+    assert {k: tuple(v.shape) for k, v in rel.state_dict().items()} == {"pos_proj.0.weight": (8, 64, 1, 1), "pos_proj.0.bias": (8,)}
+    rel.load_state_dict({"pos_proj.0.weight": T(g["proj_weight"]), "pos_proj.0.bias": T(g["proj_bias"])})
+    np.testing.assert_allclose(rd.box_rel_encoding(T(g["src"]), T(g["tgt"])).numpy(), g["enc"], atol=1e-6)
+    with pytest.raises(_lib.RdetrError):
+        rel(T(g["src"]), T(g["tgt"]))                                  # CPU tensors: no fallback
+    with pytest.raises(Exception):
+        rel(torch.zeros(1, 3, 5))
+    with pytest.raises(NotImplementedError):
+        rd.PositionRelationEmbedding(16, 8, activation_layer=torch.nn.GELU)
+
+
+def test_self_attention_contract(golden):
+    g = golden("g6_self_attn.npz")
+    att = rd.RelationSelfAttention(256, 8, dropout=0.0, batch_first=True)
+    ref = torch.nn.MultiheadAttention(256, 8, dropout=0.0, batch_first=True)
+    assert {k: tuple(v.shape) for k, v in att.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    att.load_state_dict(ref.state_dict())
+    with pytest.raises(_lib.RdetrError):
+        att(query=T(g["qp"]), key=T(g["qp"]), value=T(g["vv"]), attn_mask=None, need_weights=False)
+
+
+def test_ops_reject_cpu_tensors_and_bad_levels():
+    v = torch.zeros(1, 16, 8, 32)
+    shp = torch.tensor([[4, 4]])
+    st = torch.tensor([0])
+    loc, aw = torch.zeros(1, 2, 8, 1, 4, 2), torch.zeros(1, 2, 8, 1, 4)
+    with pytest.raises(_lib.RdetrError):
+        ops.ms_deform_attn_forward(v, shp, st, loc, aw, 64)
+    with pytest.raises(_lib.RdetrError):
+        ops.bias_softmax_(torch.zeros(2, 3, 4))
+    with pytest.raises(_lib.RdetrError):
+        ops.relation_bias(torch.zeros(1, 2, 4), torch.zeros(1, 2, 4), torch.zeros(8, 64), None)
+    with pytest.raises(_lib.RdetrError):
+        ops.check_levels(torch.tensor([[5, 4]]), st, 16)               # 20 positions do not fit S = 16
+    with pytest.raises(_lib.RdetrError):
+        ops.check_levels(shp.int(), st, 16)                            # wrong dtype
+    ops.check_levels(shp, st, 16)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librelation_detr_amd.so")
+    with pytest.raises(_lib.RdetrError, match="no CPU or PyTorch fallback"):
+        _lib.load()

@@ -138,7 +138,9 @@ def cpu_baseline(Nq, budget_s=25.0):
     """The oracle's op-for-op PyTorch restatement of the same step on the host cores, ONE image
     (B=1), repeated until ~budget_s of CPU work; returns images/s."""
     from oracle import torch_ref
-    cores = os.cpu_count() or 1
+    # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share; more threads than
+    # that oversubscribe (measured: 62 s/image with 256 threads)
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("RDETR_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     x = build_inputs(1, Nq, "cpu", 7)
     g = torch.Generator().manual_seed(0)

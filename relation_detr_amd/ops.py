@@ -9,6 +9,7 @@ No CPU path: a tensor that is not on a ROCm device raises, and so does a missing
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -34,21 +35,26 @@ def _require_contiguous(**named: torch.Tensor) -> None:
             raise _lib.RdetrError(f"{name} tensor has to be contiguous")      # AT_ASSERTM, ms_deform_attn_cuda.cu:20-24
 
 
-# host copies of (spatial_shapes, level_start_index) keyed by storage identity: one D2H sync per new
-# pyramid instead of one per call (the reference syncs on every call, ms_deform_attn.py:313).
+# Host copies of (spatial_shapes, level_start_index), cached per tensor OBJECT (weak references, so
+# a recycled device address can never alias a stale entry): one D2H sync per new pyramid instead of
+# one per call (the reference syncs on every call, ms_deform_attn.py:313).
 _shape_cache: dict = {}
 
 
 def host_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor) -> Tuple[tuple, tuple]:
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, level_start_index.data_ptr(),
-           level_start_index._version, str(spatial_shapes.device), tuple(spatial_shapes.shape))
+    key = (id(spatial_shapes), id(level_start_index))
     hit = _shape_cache.get(key)
-    if hit is None:
-        if len(_shape_cache) > 64:
-            _shape_cache.clear()
-        hit = (tuple(map(tuple, spatial_shapes.tolist())), tuple(level_start_index.tolist()))
-        _shape_cache[key] = hit
-    return hit
+    if hit is not None:
+        ref_s, ref_l, ver, levels = hit
+        if ref_s() is spatial_shapes and ref_l() is level_start_index and ver == (spatial_shapes._version,
+                                                                                 level_start_index._version):
+            return levels
+    if len(_shape_cache) > 64:
+        _shape_cache.clear()
+    levels = (tuple(map(tuple, spatial_shapes.tolist())), tuple(level_start_index.tolist()))
+    _shape_cache[key] = (weakref.ref(spatial_shapes), weakref.ref(level_start_index),
+                         (spatial_shapes._version, level_start_index._version), levels)
+    return levels
 
 
 def check_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, num_value: int) -> None:

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Run only the encoder-shape MSDA gather kernel (BASELINE.json configs[1]: B=4, S=Nq=22,323, 4 levels)
+so that rocprofv3 traces / PMC passes of it stay small.
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/profile_msda.py [fp32|bf16] [reps]
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/y -- python3 tools/profile_msda.py fp32 5
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    dtype = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    dev = torch.device("cuda", 0)
+    x = bench.build_inputs(B, 900, dev, 1000)
+    t = bench.time_encoder_kernel(x, B, dtype, reps=reps)
+    alg = bench.msda_algorithmic_bytes(B, x["S"], x["S"], x["L"], 4, 8, 32, 2 if dtype == torch.bfloat16 else 4)
+    print(f"{dtype} B={B}: {t*1e6:.1f} us/launch, algorithmic {alg/1e6:.1f} MB -> {alg/t/1e9:.0f} GB/s ({alg/t/8e12*100:.1f}% of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()

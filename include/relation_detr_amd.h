@@ -48,8 +48,8 @@ const char *rdetr_status_string(int status);
  *   attn_weight    [B, Nq, H, L, P]    fp32 (already soft-maxed over L*P by the caller)
  *   out            [B, Nq, H*D]        channel = head*D + c
  *
- * Fast path: H*D*sizeof(T) a multiple of 16 bytes, D in {32} and H <= 8 ... see rdetr_msda_fast_path();
- * any other (H, D) runs a generic one-thread-per-output kernel.  There is no im2col_step batch
+ * Fast path (H = 8, D = 32, P = 4, L <= 8, see rdetr_msda_fast_path()): the query-run kernel of
+ * csrc/msda_fwd.hip; any other (H, D, P) runs a generic one-thread-per-output kernel.  There is no im2col_step batch
  * restriction (the reference requires B % min(B, 64) == 0, ms_deform_attn_cuda.cu:42-44).
  * NaN sampling locations contribute zero (the CUDA op's guard, ms_deform_im2col_cuda.cuh:277).
  * The bf16 variant stores value and out as bfloat16 and keeps locations, weights and the
@@ -63,7 +63,26 @@ int rdetr_msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes
                             const float *sampling_loc, const float *attn_weight, int B, int S, int H, int D,
                             int L, int Nq, int P, uint16_t *out, void *stream);
 
-/* 1 if (H, D, L, P) is served by the wave-per-query kernel, 0 if by the generic kernel. */
+/* Same operator with the sampling-location producer fused in.
+ * Replaces lines 322-349 + the core call of MultiScaleDeformableAttention.forward
+ * (models/bricks/ms_deform_attn.py): the caller passes the RAW outputs of the two query projections,
+ *   sampling_offsets [B, Nq, H, L, P, 2]   attn_logits [B, Nq, H, L*P]   (dtype of value: fp32 / bf16)
+ *   reference_points [B, Nq, L, ref_dim] fp32, ref_dim 2 (x,y) or 4 (cx,cy,w,h)
+ * and the kernel performs softmax over L*P and  loc = ref + off/(W_l,H_l)  (ref_dim 2)  or
+ * ref_xy + off/P * ref_wh * 0.5  (ref_dim 4)  in its set-up phase -- locations and weights never
+ * exist in HBM.  Fast-path shapes only (rdetr_msda_fast_path() == 1); otherwise RDETR_ERR_UNSUPPORTED
+ * and the caller uses rdetr_msda_forward_* with materialised locations / weights. */
+int rdetr_msda_forward_fused_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                 const float *sampling_offsets, const float *attn_logits,
+                                 const float *reference_points, int ref_dim, int B, int S, int H, int D, int L, int Nq,
+                                 int P, float *out, void *stream);
+
+int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                  const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B, int S,
+                                  int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
+
+/* 1 if (H, D, L, P) is served by the query-run kernel, 0 if by the generic kernel. */
 int rdetr_msda_fast_path(int H, int D, int L, int P);
 
 /* ---------------------------------------------------------------------------------------------

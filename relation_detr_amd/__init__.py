@@ -7,10 +7,10 @@ from .ms_deform_attn import MultiScaleDeformableAttention
 from .relation import PositionRelationEmbedding, PositionRelationEncoder, box_rel_encoding
 from .self_attn import RelationSelfAttention
 from .ops import (MultiScaleDeformableAttnFunction, bias_softmax_, ms_deform_attn_backward, ms_deform_attn_forward,
-                  relation_bias)
+                  ms_deform_attn_forward_fused, relation_bias)
 
 __all__ = [
     "MultiScaleDeformableAttention", "PositionRelationEmbedding", "PositionRelationEncoder", "box_rel_encoding",
     "RelationSelfAttention", "MultiScaleDeformableAttnFunction", "ms_deform_attn_forward",
-    "ms_deform_attn_backward", "relation_bias", "bias_softmax_",
+    "ms_deform_attn_forward_fused", "ms_deform_attn_backward", "relation_bias", "bias_softmax_",
 ]

@@ -4,20 +4,24 @@
 // (models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:226-288: one thread per output scalar, every
 // thread re-reading the 16 (loc, weight) triples of its head and issuing 64 scattered 4-byte loads).
 //
-// Design (wave-per-query kernel, H = 8 heads x D = 32 channels, P = 4 points, L <= 8 levels):
-//   * one 64-lane wavefront owns one query (b, q); lane = head*8 + sub, the lane accumulates the
-//     4 channels [4*sub, 4*sub+4) of its head in registers, so a wave's gather instruction reads
-//     eight full 128-byte head rows (fp32) -- one per head -- of the level-packed value tensor;
-//   * the per-(head, point) bilinear set-up (pixel coords, 4 corner byte offsets, 4 corner weights
+// Design ("query-run" kernel, H = 8 heads x D = 32 channels, P = 4 points, L <= 8 levels):
+//   * one 64-lane wavefront owns ONE head and a run of consecutive queries: 8 queries x 8 lanes (fp32,
+//     a lane holds 4 channels = 16 B of the 128-byte head row) or 16 queries x 4 lanes (bf16, 8 channels
+//     = 16 B of the 64-byte head row).  Every gather is a 16-byte-per-lane buffer_load_dwordx4: the
+//     texture addresser processes 4 lanes per clock whatever the width, so narrower loads only waste it.
+//     In the encoder consecutive queries are neighbouring pixels, so the rows one instruction reads are
+//     neighbouring rows of one head plane and the x0 / x0+1 corner instructions re-use each other's lines
+//     (measured 12 % faster than a one-query-x-eight-heads mapping, which reads eight unrelated rows);
+//   * the per-(query, point) bilinear set-up (pixel coords, 4 corner byte offsets, 4 corner weights
 //     already multiplied by the attention weight) is computed ONCE by one lane and staged in LDS,
-//     then broadcast to the 8 lanes of the head with two conflict-free ds_read_b128 per point;
+//     then broadcast to the lanes of the row with two conflict-free ds_read_b128 per point;
 //   * corners outside the level get the byte offset 0x80000000: the buffer descriptor's range
 //     check returns 0 for them without a memory access, which is exactly the zero-padding rule of
 //     ms_deform_im2col_cuda.cuh:44-67, so the inner loop has no branches;
-//   * the value tensor of image b is addressed through one wave-uniform buffer descriptor with
+//   * the (image, head) plane is addressed through one wave-uniform buffer descriptor with
 //     32-bit byte offsets (S*H*D*sizeof(T) < 2^31 is checked on the host);
 //   * hardware block ids are remapped so that each XCD (private L2) owns a contiguous range of
-//     queries (common.h: xcd_contiguous_block).
+//     (image, head, query-tile) blocks (common.h: xcd_contiguous_block).
 // Any other (H, D, P) runs msda_fwd_generic_kernel (one thread per output, 64-bit indexing).
 #include "common.h"
 
@@ -39,57 +43,93 @@ struct LevelTable {
 template <typename T> struct ValueIO;
 
 template <> struct ValueIO<float> {
-    static constexpr unsigned kLaneBytes = 16;                       // 4 channels x fp32
+    static constexpr int kRunSub = 8, kRunCh = 4;                    // 8 lanes x 4 channels (16 B) per 128-byte head row
     static constexpr unsigned kHeadBytes = kHeadDim * 4;             // 128 B: one cache line per head row
     static constexpr unsigned kPixelBytes = kHeads * kHeadBytes;     // 1 KiB per pixel
-    static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+    static __device__ __forceinline__ void load_run(__amdgpu_buffer_rsrc_t rsrc, unsigned off, float (&v)[4])
     {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        const f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
     }
-    static __device__ __forceinline__ void store(float *row, int lane, f32x4 acc)
+    static __device__ __forceinline__ void store_run(float *p, const float (&a)[4])
     {
-        reinterpret_cast<f32x4 *>(row)[lane] = acc;
+        *reinterpret_cast<f32x4 *>(p) = f32x4{a[0], a[1], a[2], a[3]};
     }
 };
 
 template <> struct ValueIO<uint16_t> {                               // bf16 storage, fp32 math
-    static constexpr unsigned kLaneBytes = 8;
+    static constexpr int kRunSub = 4, kRunCh = 8;                    // 4 lanes x 8 channels (16 B) per 64-byte head row
     static constexpr unsigned kHeadBytes = kHeadDim * 2;
     static constexpr unsigned kPixelBytes = kHeads * kHeadBytes;     // 512 B per pixel
-    static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t rsrc, unsigned off)
+    static __device__ __forceinline__ void load_run(__amdgpu_buffer_rsrc_t rsrc, unsigned off, float (&v)[8])
     {
-        const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
-        f32x4 v;
-        v.x = __builtin_bit_cast(float, r.x << 16);
-        v.y = __builtin_bit_cast(float, r.x & 0xffff0000u);
-        v.z = __builtin_bit_cast(float, r.y << 16);
-        v.w = __builtin_bit_cast(float, r.y & 0xffff0000u);
-        return v;
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+        v[4] = __builtin_bit_cast(float, r.z << 16); v[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
+        v[6] = __builtin_bit_cast(float, r.w << 16); v[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
     }
-    static __device__ __forceinline__ void store(uint16_t *row, int lane, f32x4 acc)
+    static __device__ __forceinline__ void store_run(uint16_t *p, const float (&a)[8])
     {
-        u32x2 p;
-        p.x = f32_to_bf16_bits(acc.x) | (f32_to_bf16_bits(acc.y) << 16);
-        p.y = f32_to_bf16_bits(acc.z) | (f32_to_bf16_bits(acc.w) << 16);
-        reinterpret_cast<u32x2 *>(row)[lane] = p;
+        u32x4 o;
+        o.x = f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16);
+        o.y = f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16);
+        o.z = f32_to_bf16_bits(a[4]) | (f32_to_bf16_bits(a[5]) << 16);
+        o.w = f32_to_bf16_bits(a[6]) | (f32_to_bf16_bits(a[7]) << 16);
+        *reinterpret_cast<u32x4 *>(p) = o;
     }
 };
 
+// Query-side scalar loads: the producer inputs (sampling offsets / attention logits) arrive in the
+// dtype of the projection that made them: fp32, or bf16 under autocast.
+template <typename Q> __device__ __forceinline__ float load_q(const Q *p);
+template <> __device__ __forceinline__ float load_q<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float load_q<uint16_t>(const uint16_t *p) { return bf16_bits_to_f32(*p); }
+template <typename Q> __device__ __forceinline__ f32x2 load_q2(const Q *p);
+template <> __device__ __forceinline__ f32x2 load_q2<float>(const float *p) { return *reinterpret_cast<const f32x2 *>(p); }
+template <> __device__ __forceinline__ f32x2 load_q2<uint16_t>(const uint16_t *p)
+{
+    const unsigned u = *reinterpret_cast<const unsigned *>(p);
+    return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+
+template <int WIDTH> __device__ __forceinline__ float group_max(float v)
+{
+#pragma unroll
+    for (int o = 1; o < WIDTH; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int o = 1; o < WIDTH; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // LT = compile-time level count (4, 5) or 0 for a run-time L in [1, 8].
-template <typename T, int LT>
-__global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_wave_kernel(
+// FUSED = false: `src_a` = sampling locations fp32 [B,Nq,H,L,P,2], `src_b` = soft-maxed weights fp32 [B,Nq,H,L,P]
+//                (the reference operator's inputs, ms_deform_attn_cuda.cu:12-19).
+// FUSED = true : `src_a` = raw sampling offsets [B,Nq,H,L,P,2], `src_b` = raw attention logits [B,Nq,H,L*P], both in
+//                value's dtype, `ref` = reference points fp32 [B,Nq,L,ref_dim]; the softmax over L*P and
+//                loc = ref + off/(W,H)  |  ref_xy + off/P * ref_wh * 0.5  (ms_deform_attn.py:326-349) happen in the
+//                set-up phase, so neither locations nor weights ever exist in HBM.
+template <typename T, int LT, bool FUSED>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
-    const float *__restrict__ loc, const float *__restrict__ attn, int S, int L_rt, int Nq, int tiles_per_image,
-    int queries_per_wave, int nblk, T *__restrict__ out)
+    const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
+    int L_rt, int Nq, int tiles_per_image, int nblk, T *__restrict__ out)
 {
     using IO = ValueIO<T>;
+    constexpr int kSub = IO::kRunSub;            // lanes per head row
+    constexpr int kCh = IO::kRunCh;              // channels per lane (16 bytes)
+    constexpr int kSlots = kWave / kSub;         // queries per wave (8 fp32, 16 bf16)
+    constexpr int kPtsPerLane = LT ? (LT * kPoints + kSub - 1) / kSub : (kMaxLevels * kPoints) / kSub;
     const int L = LT ? LT : L_rt;
     const int LP = L * kPoints;
 
     __shared__ LevelTable lvl;
-    // staging per wave: [point][head] -> {4 corner byte offsets, 4 corner weights}
-    __shared__ u32x4 stage_off[kWavesPerBlock][kMaxLevels * kPoints * kHeads];
-    __shared__ f32x4 stage_wgt[kWavesPerBlock][kMaxLevels * kPoints * kHeads];
+    __shared__ u32x4 stage_off[kWavesPerBlock][kMaxLevels * kPoints * kSlots];
+    __shared__ f32x4 stage_wgt[kWavesPerBlock][kMaxLevels * kPoints * kSlots];
 
     const int tid = threadIdx.x;
     if (tid < L) {
@@ -99,38 +139,86 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_wave_kernel(
     }
     __syncthreads();
 
+    // logical block -> (image b, head m, tile of consecutive queries); tiles of one (b, m) are consecutive
     const int logical = xcd_contiguous_block(blockIdx.x, nblk);
-    const int b = logical / tiles_per_image;
-    const int tile = logical - b * tiles_per_image;
+    const int bm = logical / tiles_per_image;
+    const int tile = logical - bm * tiles_per_image;
+    const int b = bm / kHeads, m = bm - b * kHeads;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int m = lane >> 3;          // head
-    const int sub = lane & 7;         // which 4-channel slice of the head / which staged points
+    const int qs = lane / kSub, sub = lane % kSub;
+    const int q = (tile * kWavesPerBlock + wave) * kSlots + qs;
+    const bool qok = q < Nq;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T *>(value) + (size_t)b * S * (kHeads * kHeadDim), 0, (unsigned)S * IO::kPixelBytes, 0x00020000);
-    const unsigned lane_off = (unsigned)m * IO::kHeadBytes + (unsigned)sub * IO::kLaneBytes;
+        const_cast<T *>(value) + (size_t)b * S * (kHeads * kHeadDim) + m * kHeadDim, 0,
+        (unsigned)S * IO::kPixelBytes - (unsigned)m * IO::kHeadBytes, 0x00020000);
+    const unsigned lane_off = (unsigned)sub * 16u;
 
     u32x4 *soff = stage_off[wave];
     f32x4 *swgt = stage_wgt[wave];
+    const size_t row = (size_t)b * Nq + (qok ? q : 0);
+    const size_t hrow = (row * kHeads + m) * (size_t)LP;
 
-    const int q_begin = (tile * kWavesPerBlock + wave) * queries_per_wave;
-    for (int qi = 0; qi < queries_per_wave; ++qi) {
-        const int q = q_begin + qi;
-        if (q >= Nq) break;                                   // wave-uniform
-        const size_t row = (size_t)b * Nq + q;
-        const float *loc_q = loc + (row * kHeads + m) * (size_t)LP * 2;
-        const float *att_q = attn + (row * kHeads + m) * (size_t)LP;
-
-        // ---- set-up: each lane prepares points sub, sub+8, ... of its head -----------------------
-        for (int pt = sub; pt < LP; pt += 8) {
-            const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc_q + 2 * pt);
-            const float a = att_q[pt];
+    // ---- set-up: lane (qs, sub) prepares points sub, sub+kSub, ... of query qs ---------------------
+    float pa[kPtsPerLane];
+    f32x2 pxy[kPtsPerLane];
+    if constexpr (FUSED) {
+        const T *off_q = static_cast<const T *>(src_a) + hrow * 2;
+        const T *lg_q = static_cast<const T *>(src_b) + hrow;
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < kPtsPerLane; ++k) {
+            const int pt = sub + k * kSub;
+            const bool ok = pt < LP;
+            pa[k] = ok ? load_q<T>(lg_q + pt) : -__builtin_inff();
+            pxy[k] = ok ? load_q2<T>(off_q + 2 * pt) : f32x2{0.f, 0.f};
+            mx = fmaxf(mx, pa[k]);
+        }
+        mx = group_max<kSub>(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < kPtsPerLane; ++k) {
+            pa[k] = expf(pa[k] - mx);            // exp(-inf) = 0 for the padding slots
+            sum += pa[k];
+        }
+        sum = group_sum<kSub>(sum);
+#pragma unroll
+        for (int k = 0; k < kPtsPerLane; ++k) {
+            const int pt = sub + k * kSub;
+            const int l = (pt < LP ? pt : 0) / kPoints;
+            const float *rp = ref + (row * L + l) * (size_t)ref_dim;
+            pa[k] = pa[k] / sum;
+            if (ref_dim == 2) {
+                pxy[k].x = rp[0] + pxy[k].x / (float)lvl.w[l];
+                pxy[k].y = rp[1] + pxy[k].y / (float)lvl.h[l];
+            } else {
+                pxy[k].x = rp[0] + pxy[k].x * (1.0f / kPoints) * rp[2] * 0.5f;
+                pxy[k].y = rp[1] + pxy[k].y * (1.0f / kPoints) * rp[3] * 0.5f;
+            }
+        }
+    } else {
+        const float *loc_q = static_cast<const float *>(src_a) + hrow * 2;
+        const float *att_q = static_cast<const float *>(src_b) + hrow;
+#pragma unroll
+        for (int k = 0; k < kPtsPerLane; ++k) {
+            const int pt = sub + k * kSub;
+            const bool ok = pt < LP;
+            pxy[k] = ok ? *reinterpret_cast<const f32x2 *>(loc_q + 2 * pt) : f32x2{0.f, 0.f};
+            pa[k] = ok ? att_q[pt] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPtsPerLane; ++k) {
+        const int pt = sub + k * kSub;
+        if (pt < LP) {
+            const f32x2 xy = pxy[k];
+            const float a = pa[k];
             const int l = pt / kPoints;
             const int h = lvl.h[l], w = lvl.w[l];
             const float x = xy.x * (float)w - 0.5f;
             const float y = xy.y * (float)h - 0.5f;
-            const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);   // false for NaN
+            const bool inside = qok && (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);   // false for NaN
             const float xf = floorf(x), yf = floorf(y);
             const int x0 = inside ? (int)xf : 0, y0 = inside ? (int)yf : 0;
             const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
@@ -148,35 +236,38 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_wave_kernel(
             wt.y = inside ? hy * lx * a : 0.f;
             wt.z = inside ? ly * hx * a : 0.f;
             wt.w = inside ? ly * lx * a : 0.f;
-            soff[pt * kHeads + m] = o;
-            swgt[pt * kHeads + m] = wt;
+            soff[pt * kSlots + qs] = o;
+            swgt[pt * kSlots + qs] = wt;
         }
-        // staging is private to this wave: LDS ops of one wave complete in order, so a wave-level
-        // fence (no s_barrier) is all that is needed between the writes above and the reads below.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- gather + weighted sum --------------------------------------------------------------
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int pt = 0; pt < LP; ++pt) {
-            const u32x4 o = soff[pt * kHeads + m];
-            const f32x4 wt = swgt[pt * kHeads + m];
-            const f32x4 v00 = IO::load(rsrc, o.x + lane_off);
-            const f32x4 v01 = IO::load(rsrc, o.y + lane_off);
-            const f32x4 v10 = IO::load(rsrc, o.z + lane_off);
-            const f32x4 v11 = IO::load(rsrc, o.w + lane_off);
-            acc += wt.x * v00;
-            acc += wt.y * v01;
-            acc += wt.z * v10;
-            acc += wt.w * v11;
-        }
-        IO::store(out + row * (kHeads * kHeadDim), lane, acc);
-
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads done before the next query's writes
-        __builtin_amdgcn_wave_barrier();
     }
+    // staging is private to this wave: LDS ops of one wave complete in order, so a wave-level
+    // fence (no s_barrier) is all that is needed between the writes above and the reads below.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    float acc[kCh];
+#pragma unroll
+    for (int c = 0; c < kCh; ++c) acc[c] = 0.f;
+    constexpr int kUnroll = 16 / kCh;            // 16 loads in flight per lane for fp32, 8 (x 16 B) for bf16
+#pragma unroll kUnroll
+    for (int pt = 0; pt < LP; ++pt) {
+        const u32x4 o = soff[pt * kSlots + qs];
+        const f32x4 wt = swgt[pt * kSlots + qs];
+        float v00[kCh], v01[kCh], v10[kCh], v11[kCh];
+        IO::load_run(rsrc, o.x + lane_off, v00);
+        IO::load_run(rsrc, o.y + lane_off, v01);
+        IO::load_run(rsrc, o.z + lane_off, v10);
+        IO::load_run(rsrc, o.w + lane_off, v11);
+#pragma unroll
+        for (int c = 0; c < kCh; ++c) {
+            acc[c] += wt.x * v00[c];
+            acc[c] += wt.y * v01[c];
+            acc[c] += wt.z * v10[c];
+            acc[c] += wt.w * v11[c];
+        }
+    }
+    if (qok) IO::store_run(out + row * (kHeads * kHeadDim) + m * kHeadDim + sub * kCh, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -234,45 +325,53 @@ static bool fast_path(int H, int D, int L, int P)
     return H == kHeads && D == kHeadDim && P == kPoints && L >= 1 && L <= kMaxLevels;
 }
 
-template <typename T>
-static int msda_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
-                        const float *attn, int B, int S, int H, int D, int L, int Nq, int P, T *out,
-                        hipStream_t stream)
+template <typename T, bool FUSED>
+static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
+                        const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
+                        int S, int L, int Nq, int tiles, int nblk, T *out)
+{
+    if (L == 4)
+        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out);
+    else if (L == 5)
+        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out);
+    else
+        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out);
+}
+
+// FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
+// FUSED = true : src_a / src_b = raw offsets / logits in T, ref = reference points; fast-path shapes only.
+template <typename T, bool FUSED>
+static int msda_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
+                        const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
+                        int P, T *out, hipStream_t stream)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
+    if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
     if (B == 0 || Nq == 0) return RDETR_OK;
-    if (!value || !shapes || !level_start || !loc || !attn || !out) return RDETR_ERR_INVALID_ARG;
+    if (!value || !shapes || !level_start || !src_a || !src_b || !out || (FUSED && !ref)) return RDETR_ERR_INVALID_ARG;
     if (S == 0) return RDETR_ERR_INVALID_ARG;
 
     const long long pixel_bytes = (long long)H * D * (long long)sizeof(T);
     const bool aligned = (reinterpret_cast<uintptr_t>(value) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
-                         (reinterpret_cast<uintptr_t>(loc) % 8 == 0);
+                         (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
-        // 4 queries per wave amortise the level-table load and give each block 16 neighbouring
-        // queries; small problems (decoder, Nq = 300..900) drop to 1 so the grid still covers the chip.
-        int qpw = 4;
-        while (qpw > 1 && (long long)B * ((Nq + kWavesPerBlock * qpw - 1) / (kWavesPerBlock * qpw)) < 2048) qpw >>= 1;
-        const int qpb = kWavesPerBlock * qpw;
+        const int qpb = kWavesPerBlock * (kWave / ValueIO<T>::kRunSub);      // queries per block (32 fp32 / 64 bf16)
         const int tiles = (Nq + qpb - 1) / qpb;
-        const long long nblk = (long long)B * tiles;
+        const long long nblk = (long long)B * H * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
-        dim3 grid((unsigned)nblk), block(kWavesPerBlock * kWave);
-        if (L == 4)
-            hipLaunchKernelGGL((msda_fwd_wave_kernel<T, 4>), grid, block, 0, stream, value, shapes, level_start, loc,
-                               attn, S, L, Nq, tiles, qpw, (int)nblk, out);
-        else if (L == 5)
-            hipLaunchKernelGGL((msda_fwd_wave_kernel<T, 5>), grid, block, 0, stream, value, shapes, level_start, loc,
-                               attn, S, L, Nq, tiles, qpw, (int)nblk, out);
-        else
-            hipLaunchKernelGGL((msda_fwd_wave_kernel<T, 0>), grid, block, 0, stream, value, shapes, level_start, loc,
-                               attn, S, L, Nq, tiles, qpw, (int)nblk, out);
+        launch_qrun<T, FUSED>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
+                              src_a, src_b, ref, ref_dim, S, L, Nq, tiles, (int)nblk, out);
         return launch_status();
     }
+    if (FUSED) return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
     const long long total = (long long)B * Nq * H * D;
     const long long want = (total + 255) / 256;
     dim3 grid((unsigned)(want < 16384 ? want : 16384)), block(256);
-    hipLaunchKernelGGL((msda_fwd_generic_kernel<T>), grid, block, 0, stream, value, shapes, level_start, loc, attn, S,
-                       H, D, L, Nq, P, total, out);
+    hipLaunchKernelGGL((msda_fwd_generic_kernel<T>), grid, block, 0, stream, value, shapes, level_start,
+                       static_cast<const float *>(src_a), static_cast<const float *>(src_b), S, H, D, L, Nq, P, total, out);
     return launch_status();
 }
 
@@ -285,8 +384,8 @@ extern "C" int rdetr_msda_forward_f32(const float *value, const int64_t *spatial
                                       const float *attn_weight, int B, int S, int H, int D, int L, int Nq, int P,
                                       float *out, void *stream)
 {
-    return rdetr::msda_forward<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, B, S, H, D,
-                                      L, Nq, P, out, static_cast<hipStream_t>(stream));
+    return rdetr::msda_forward<float, false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr,
+                                             0, B, S, H, D, L, Nq, P, out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rdetr_msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
@@ -294,6 +393,26 @@ extern "C" int rdetr_msda_forward_bf16(const uint16_t *value, const int64_t *spa
                                        const float *attn_weight, int B, int S, int H, int D, int L, int Nq, int P,
                                        uint16_t *out, void *stream)
 {
-    return rdetr::msda_forward<uint16_t>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, B, S, H,
-                                         D, L, Nq, P, out, static_cast<hipStream_t>(stream));
+    return rdetr::msda_forward<uint16_t, false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                                nullptr, 0, B, S, H, D, L, Nq, P, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_forward_fused_f32(const float *value, const int64_t *spatial_shapes,
+                                            const int64_t *level_start_index, const float *sampling_offsets,
+                                            const float *attn_logits, const float *reference_points, int ref_dim, int B,
+                                            int S, int H, int D, int L, int Nq, int P, float *out, void *stream)
+{
+    return rdetr::msda_forward<float, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                            reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                             const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                             const uint16_t *attn_logits, const float *reference_points, int ref_dim,
+                                             int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream)
+{
+    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                               reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                               static_cast<hipStream_t>(stream));
 }

@@ -73,10 +73,8 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.zeros_(self.output_proj.bias)
 
-    def project_inputs(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
-                       key_padding_mask):
-        """Everything before the core: value projection (+ padding zero-fill), offsets, soft-maxed
-        weights, sampling locations.  Pure torch (dense GEMMs + elementwise), device-agnostic."""
+    def _projections(self, query: Tensor, value: Tensor, key_padding_mask):
+        """value projection (+ padding zero-fill, ms_deform_attn.py:316-321) and the two raw query projections."""
         B, Nq, _ = query.shape
         S = value.shape[1]
         H, L, P = self.num_heads, self.num_levels, self.num_points
@@ -85,8 +83,16 @@ class MultiScaleDeformableAttention(nn.Module):
             v = v.masked_fill(key_padding_mask[..., None], float(0))
         v = v.view(B, S, H, self.embed_dim // H)
         offsets = self.sampling_offsets(query).view(B, Nq, H, L, P, 2)
-        weights = self.attention_weights(query).view(B, Nq, H, L * P).softmax(-1).view(B, Nq, H, L, P)
-        return v, sampling_locations(reference_points, offsets, spatial_shapes, P), weights
+        logits = self.attention_weights(query).view(B, Nq, H, L * P)
+        return v, offsets, logits
+
+    def project_inputs(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
+                       key_padding_mask):
+        """Everything before the core, materialised (the reference's own sequence, ms_deform_attn.py:316-349):
+        projected value, sampling locations, soft-maxed weights.  Pure torch, device-agnostic."""
+        v, offsets, logits = self._projections(query, value, key_padding_mask)
+        weights = logits.softmax(-1).view(*offsets.shape[:5])
+        return v, sampling_locations(reference_points, offsets, spatial_shapes, self.num_points), weights
 
     def forward(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
                 level_start_index: Tensor, key_padding_mask: Tensor) -> Tensor:
@@ -95,11 +101,25 @@ class MultiScaleDeformableAttention(nn.Module):
         if value.is_cuda:      # same consistency check as the reference (:313), from a cached host copy
             shapes, _ = ops.host_levels(spatial_shapes, level_start_index)
             assert sum(h * w for h, w in shapes) == value.shape[1]
-        v, loc, weights = self.project_inputs(query, reference_points, value, spatial_shapes, key_padding_mask)
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError(
+                "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
+        v, offsets, logits = self._projections(query, value, key_padding_mask)
         core_dtype = v.dtype if v.dtype in (torch.float32, torch.bfloat16) else torch.float32
-        core = ops.MultiScaleDeformableAttnFunction.apply(
-            v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, loc.float().contiguous(),
-            weights.float().contiguous(), self.im2col_step)
+        needs_grad = torch.is_grad_enabled() and any(
+            t.requires_grad for t in (v, offsets, logits, reference_points))
+        if (v.is_cuda and not needs_grad
+                and ops.msda_fast_path(self.num_heads, self.embed_dim // self.num_heads, self.num_levels, self.num_points)):
+            # inference: softmax + location arithmetic happen inside the gather kernel's set-up phase
+            core = ops.ms_deform_attn_forward_fused(
+                v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype).contiguous(),
+                logits.to(core_dtype).contiguous(), reference_points.float().contiguous())
+        else:
+            weights = logits.softmax(-1).view(*offsets.shape[:5])
+            loc = sampling_locations(reference_points, offsets, spatial_shapes, self.num_points)
+            core = ops.MultiScaleDeformableAttnFunction.apply(
+                v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, loc.float().contiguous(),
+                weights.float().contiguous(), self.im2col_step)
         if core.dtype != v.dtype:
             core = core.to(v.dtype)
         return self.output_proj(core)

@@ -103,6 +103,49 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
     return out
 
 
+def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
+                                 sampling_offsets: torch.Tensor, attn_logits: torch.Tensor,
+                                 reference_points: torch.Tensor) -> torch.Tensor:
+    """MSDA with the location / weight producer fused into the gather kernel (inference path).
+    value [B,S,H,D] fp32|bf16; sampling_offsets [B,Nq,H,L,P,2] and attn_logits [B,Nq,H,L*P] RAW projection
+    outputs in value's dtype; reference_points [B,Nq,L,2|4] fp32 -> [B,Nq,H*D] in value's dtype.
+    Same result as softmax + sampling-location arithmetic + ms_deform_attn_forward (ms_deform_attn.py:322-370)."""
+    _require_device(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points)
+    _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                        sampling_offsets=sampling_offsets, attn_logits=attn_logits, reference_points=reference_points)
+    if value.dim() != 4 or sampling_offsets.dim() != 6 or reference_points.dim() != 4:
+        raise _lib.RdetrError("expected value [B,S,H,D], sampling_offsets [B,Nq,H,L,P,2], reference_points [B,Nq,L,2|4]")
+    B, S, H, D = value.shape
+    _, Nq, H2, L, P, two = sampling_offsets.shape
+    ref_dim = reference_points.shape[-1]
+    if (H2, two) != (H, 2) or sampling_offsets.shape[0] != B or attn_logits.numel() != B * Nq * H * L * P:
+        raise _lib.RdetrError("sampling_offsets / attn_logits shapes do not match value")
+    if tuple(reference_points.shape[:3]) != (B, Nq, L) or ref_dim not in (2, 4):
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(ref_dim))
+    if sampling_offsets.dtype != value.dtype or attn_logits.dtype != value.dtype or reference_points.dtype != torch.float32:
+        raise _lib.RdetrError("sampling_offsets / attn_logits must have value's dtype, reference_points float32")
+    if spatial_shapes.shape[0] != L:
+        raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_offsets")
+    check_levels(spatial_shapes, level_start_index, S)
+    lib = _lib.load()
+    if value.dtype == torch.float32:
+        fn = lib.rdetr_msda_forward_fused_f32
+    elif value.dtype == torch.bfloat16:
+        fn = lib.rdetr_msda_forward_fused_bf16
+    else:
+        raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
+    out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
+            attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, B, S, H, D, L, Nq, P, out.data_ptr(),
+            _stream_ptr(value))
+    _lib.check(st, "rdetr_msda_forward_fused")
+    return out
+
+
+def msda_fast_path(H: int, D: int, L: int, P: int) -> bool:
+    return bool(_lib.load().rdetr_msda_fast_path(H, D, L, P))
+
+
 def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
                             sampling_loc: torch.Tensor, attn_weight: torch.Tensor, grad_output: torch.Tensor,
                             im2col_step: int = 64):

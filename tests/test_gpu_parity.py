@@ -317,3 +317,53 @@ def test_full_size_properties(rd):
     const = torch.arange(256, dtype=torch.float32, device=DEV).view(1, 1, 8, 32).expand(B, S, 8, 32).contiguous() / 64
     oc = rd.ms_deform_attn_forward(const, shp_d, start_d, loc, attn, 64)
     assert (oc - const[:, :1].reshape(B, 1, 256)).abs().max().item() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ fused producer
+@pytest.mark.parametrize("L,ref_dim,dtype", [(4, 2, torch.float32), (4, 4, torch.float32), (5, 2, torch.float32),
+                                             (3, 4, torch.float32), (4, 2, torch.bfloat16), (4, 4, torch.bfloat16)])
+def test_msda_fused_producer_matches_unfused(rd, L, ref_dim, dtype):
+    """softmax + location arithmetic inside the kernel == the reference's materialised sequence
+    (ms_deform_attn.py:322-349) followed by the plain operator / the oracle."""
+    from oracle import torch_ref
+    shapes_l = [(23, 37), (12, 19), (6, 10), (3, 5), (2, 3)][:L]
+    shp, start, S = pyramid(shapes_l)
+    g = torch.Generator().manual_seed(100 + L * 10 + ref_dim)
+    B, Nq = 2, 75
+    value = torch.randn(B, S, 8, 32, generator=g)
+    off = torch.randn(B, Nq, 8, L, 4, 2, generator=g) * 3
+    logits = torch.randn(B, Nq, 8, L * 4, generator=g) * 2
+    if ref_dim == 2:
+        ref = torch.rand(B, Nq, L, 2, generator=g)
+    else:
+        ref = torch.cat([torch.rand(B, Nq, L, 2, generator=g), torch.rand(B, Nq, L, 2, generator=g) * 0.5 + 0.02], -1)
+    vq, oq, lq = value.to(dtype), off.to(dtype), logits.to(dtype)
+    out = rd.ms_deform_attn_forward_fused(vq.to(DEV), shp.to(DEV), start.to(DEV), oq.to(DEV), lq.to(DEV), ref.to(DEV))
+    loc = torch_ref.sampling_locations_from_reference(ref, oq.float(), shp, 4)
+    w = lq.float().softmax(-1).view(B, Nq, 8, L, 4)
+    ref_out = torch_ref.msda_core(vq.float(), shp, loc, w)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(out.cpu().numpy(), ref_out.numpy(), rtol=0, atol=1e-4)
+        plain = rd.ms_deform_attn_forward(vq.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV).contiguous(), w.to(DEV).contiguous(), 64)
+        assert (out - plain).abs().max().item() < 2e-5
+    else:
+        err = (out.float().cpu() - ref_out).abs()
+        assert (err <= 2.0 ** -8 * ref_out.abs() + 1e-3).all(), err.max()
+
+
+def test_msda_module_train_and_eval_paths_agree(rd, golden):
+    """eval (no grad) takes the fused kernel, training the autograd Function: same numbers."""
+    g = golden("g4_msda_module.npz")
+    mod = rd.MultiScaleDeformableAttention(256, 4, 8, 4)
+    mod.load_state_dict({k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")})
+    mod = mod.to(DEV)
+    kw = dict(query=T(g["q_dec"]).to(DEV), reference_points=T(g["ref4"]).to(DEV), value=T(g["feat"]).to(DEV),
+              spatial_shapes=T(g["shapes"]).to(DEV), level_start_index=T(g["level_start"]).to(DEV), key_padding_mask=None)
+    train_out = mod(**kw)
+    assert train_out.requires_grad
+    train_out.sum().backward()
+    assert mod.sampling_offsets.weight.grad is not None and torch.isfinite(mod.value_proj.weight.grad).all()
+    with torch.no_grad():
+        eval_out = mod(**kw)
+    assert (train_out.detach() - eval_out).abs().max().item() < 2e-5
+    np.testing.assert_allclose(eval_out.cpu().numpy(), g["out_dec"], rtol=0, atol=1e-4)

@@ -120,6 +120,7 @@ def time_encoder_kernel(x, B, dtype, reps=20):
     wh = x["shapes"].flip(-1).float().cpu()
     k = torch.arange(1, 5, dtype=torch.float32).view(1, 1, 1, 1, 4, 1)
     off = torch.randn(B, S, 8, L, 4, 2, generator=g) * k / wh.view(1, 1, 1, L, 1, 2)
+    off = off * float(os.environ.get("RDETR_BENCH_SPREAD", "1.0"))      # diagnostic knob, default = SURVEY 8d
     loc = (x["enc_ref"].cpu()[:, :, None, :, None, :] + off).contiguous().to(dev)
     attn = torch.softmax(torch.randn(B, S, 8, L * 4, generator=g), -1).view(B, S, 8, L, 4).contiguous().to(dev)
     for _ in range(3):

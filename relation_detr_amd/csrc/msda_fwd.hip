@@ -23,6 +23,8 @@
 //   * hardware block ids are remapped so that each XCD (private L2) owns a contiguous range of
 //     (image, head, query-tile) blocks (common.h: xcd_contiguous_block).
 // Any other (H, D, P) runs msda_fwd_generic_kernel (one thread per output, 64-bit indexing).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rdetr {
@@ -117,7 +119,7 @@ template <typename T, int LT, bool FUSED>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
-    int L_rt, int Nq, int tiles_per_image, int nblk, T *__restrict__ out)
+    int L_rt, int Nq, int tiles_per_image, int nblk, int tile2d, T *__restrict__ out)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
@@ -147,8 +149,24 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int qs = lane / kSub, sub = lane % kSub;
-    const int q = (tile * kWavesPerBlock + wave) * kSlots + qs;
-    const bool qok = q < Nq;
+    int q = (tile * kWavesPerBlock + wave) * kSlots + qs;
+    bool qok = q < Nq;
+    if (tile2d) {
+        // encoder order (queries = pyramid pixels): the block covers a kSlots-wide x 4-row patch of ONE level, one
+        // row per wave, so the rows y0+1 of wave r are the rows y0 of wave r+1: vertical re-use inside the CU's L1
+        int r = tile, lq = 0, ntx = 1;
+        for (int l = 0; l < L; ++l) {
+            ntx = (lvl.w[l] + kSlots - 1) / kSlots;
+            const int nt = ntx * ((lvl.h[l] + kWavesPerBlock - 1) / kWavesPerBlock);
+            lq = l;
+            if (r < nt) break;
+            r -= nt;
+        }
+        const int ty = r / ntx, tx = r - ty * ntx;
+        const int x = tx * kSlots + qs, y = ty * kWavesPerBlock + wave;
+        qok = x < lvl.w[lq] && y < lvl.h[lq];
+        q = qok ? lvl.start[lq] + y * lvl.w[lq] + x : 0;
+    }
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T *>(value) + (size_t)b * S * (kHeads * kHeadDim) + m * kHeadDim, 0,
@@ -328,17 +346,17 @@ static bool fast_path(int H, int D, int L, int P)
 template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
-                        int S, int L, int Nq, int tiles, int nblk, T *out)
+                        int S, int L, int Nq, int tiles, int nblk, int tile2d, T *out)
 {
     if (L == 4)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out);
     else if (L == 5)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out);
     else
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
@@ -346,7 +364,7 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
 template <typename T, bool FUSED>
 static int msda_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
                         const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
-                        int P, T *out, hipStream_t stream)
+                        int P, T *out, hipStream_t stream, const int64_t *host_shapes = nullptr)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
     if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
@@ -358,12 +376,25 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *le
     const bool aligned = (reinterpret_cast<uintptr_t>(value) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
-        const int qpb = kWavesPerBlock * (kWave / ValueIO<T>::kRunSub);      // queries per block (32 fp32 / 64 bf16)
-        const int tiles = (Nq + qpb - 1) / qpb;
+        const int slots = kWave / ValueIO<T>::kRunSub;                       // queries per wave (8 fp32 / 16 bf16)
+        const int qpb = kWavesPerBlock * slots;
+        long long tiles = (Nq + qpb - 1) / qpb;
+        int tile2d = 0;
+        if (host_shapes) {        // encoder order: 2-D patches (slots wide x 4 rows) per level instead of 1-D runs
+            long long t2 = 0, tot = 0;
+            for (int l = 0; l < L; ++l) {
+                const long long h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
+                t2 += ((w + slots - 1) / slots) * ((h + kWavesPerBlock - 1) / kWavesPerBlock);
+                tot += h * w;
+            }
+            if (tot != S || Nq != S) return RDETR_ERR_INVALID_ARG;
+            tiles = t2;
+            tile2d = 1;
+        }
         const long long nblk = (long long)B * H * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
         launch_qrun<T, FUSED>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
-                              src_a, src_b, ref, ref_dim, S, L, Nq, tiles, (int)nblk, out);
+                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, tile2d, out);
         return launch_status();
     }
     if (FUSED) return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
@@ -414,5 +445,75 @@ extern "C" int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_
 {
     return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
                                                reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                               static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder-shape entry points (Nq == S, host copy of the shape table available).  Two experimental launch
+// strategies were built and measured in round 1, selected by RDETR_MSDA_ENCODER_ALGO:
+//   "tile2d" -- query-run kernel, each workgroup = a (8|16)-wide x 4-row patch of one level;
+//   "sweep"  -- LDS sweep kernel (csrc/msda_sweep.hip);
+// anything else (default) = the plain 1-D query-run launch, which was the fastest of the three.
+namespace rdetr {
+template <typename T, bool FUSED>
+int msda_sweep_forward(const T *value, const int64_t *host_shapes, const void *src_a, const void *src_b, const float *ref,
+                       int ref_dim, int B, int S, int L, T *out, hipStream_t stream);
+
+template <typename T, bool FUSED>
+static int msda_encoder(const T *value, const int64_t *shapes, const int64_t *level_start, const int64_t *host_shapes,
+                        const void *src_a, const void *src_b, const float *ref, int ref_dim, int B, int S, int L, T *out,
+                        hipStream_t stream)
+{
+    if (!host_shapes) return RDETR_ERR_INVALID_ARG;
+    static const char algo = []() {
+        const char *e = getenv("RDETR_MSDA_ENCODER_ALGO");
+        return e ? e[0] : 'q';
+    }();
+    if (algo == 's') {
+        const int st = msda_sweep_forward<T, FUSED>(value, host_shapes, src_a, src_b, ref, ref_dim, B, S, L, out, stream);
+        if (st != RDETR_ERR_UNSUPPORTED) return st;
+    }
+    return msda_forward<T, FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, kHeads, kHeadDim, L, S,
+                                  kPoints, out, stream, algo == 't' ? host_shapes : nullptr);
+}
+}  // namespace rdetr
+
+extern "C" int rdetr_msda_encoder_forward_f32(const float *value, const int64_t *spatial_shapes,
+                                              const int64_t *level_start_index, const int64_t *host_spatial_shapes,
+                                              const float *sampling_loc, const float *attn_weight, int B, int S, int L,
+                                              float *out, void *stream)
+{
+    return rdetr::msda_encoder<float, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
+                                             attn_weight, nullptr, 0, B, S, L, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_encoder_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                               const int64_t *level_start_index, const int64_t *host_spatial_shapes,
+                                               const float *sampling_loc, const float *attn_weight, int B, int S, int L,
+                                               uint16_t *out, void *stream)
+{
+    return rdetr::msda_encoder<uint16_t, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
+                                                attn_weight, nullptr, 0, B, S, L, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_encoder_forward_fused_f32(const float *value, const int64_t *spatial_shapes,
+                                                    const int64_t *level_start_index, const int64_t *host_spatial_shapes,
+                                                    const float *sampling_offsets, const float *attn_logits,
+                                                    const float *reference_points, int ref_dim, int B, int S, int L,
+                                                    float *out, void *stream)
+{
+    return rdetr::msda_encoder<float, true>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_offsets,
+                                            attn_logits, reference_points, ref_dim, B, S, L, out,
+                                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_encoder_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                                     const int64_t *level_start_index, const int64_t *host_spatial_shapes,
+                                                     const uint16_t *sampling_offsets, const uint16_t *attn_logits,
+                                                     const float *reference_points, int ref_dim, int B, int S, int L,
+                                                     uint16_t *out, void *stream)
+{
+    return rdetr::msda_encoder<uint16_t, true>(value, spatial_shapes, level_start_index, host_spatial_shapes,
+                                               sampling_offsets, attn_logits, reference_points, ref_dim, B, S, L, out,
                                                static_cast<hipStream_t>(stream));
 }

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(kRelWaves *kWave) void relation_bias_kernel(
     if (i0 >= N1) return;
     const bool jok = j < N2;
 
-    const f32x4 t = jok ? *reinterpret_cast<const f32x4 *>(tgt + ((size_t)b * N2 + j) * 4) : f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+    // tail lanes re-read the last box (never stored); no `bool ? vec : vec` (not a whole-vector select in clang)
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(tgt + ((size_t)b * N2 + (jok ? j : N2 - 1)) * 4);
     const float tw = t.z + eps, th = t.w + eps;
 
     float es[kRelRows][4];

@@ -367,3 +367,68 @@ def test_msda_module_train_and_eval_paths_agree(rd, golden):
         eval_out = mod(**kw)
     assert (train_out.detach() - eval_out).abs().max().item() < 2e-5
     np.testing.assert_allclose(eval_out.cpu().numpy(), g["out_dec"], rtol=0, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ encoder sweep kernel
+def _pixel_refs(shapes):
+    refs = []
+    for h, w in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    return torch.cat(refs, 0)
+
+
+@pytest.mark.parametrize("shapes,B,spread_px,dtype", [
+    ([(100, 168), (50, 84), (25, 42), (13, 21)], 1, 3.0, torch.float32),     # R50 pyramid, offsets inside the band
+    ([(100, 168), (50, 84), (25, 42), (13, 21)], 1, 30.0, torch.float32),    # most samples take the fallback path
+    ([(37, 61), (19, 31), (10, 16), (5, 8), (3, 4)], 2, 4.0, torch.float32),  # odd 5-level pyramid
+    ([(9, 14), (5, 7), (3, 4)], 3, 2.0, torch.float32),                       # tiny: windows clamp to the level
+    ([(40, 33)], 1, 5.0, torch.float32),                                      # single level
+    ([(64, 96), (32, 48), (16, 24), (8, 12)], 2, 4.0, torch.bfloat16),
+])
+def test_encoder_entry_matches_oracle_and_plain_entry(rd, shapes, B, spread_px, dtype, monkeypatch):
+    """Nq == S (encoder self-attention) goes through rdetr_msda_encoder_forward_*; it must agree with the oracle
+    and, to rounding, with the shape-agnostic entry point, whatever the offsets.  tests/test_gpu_sweep.py
+    repeats this file's encoder cases in child processes with RDETR_MSDA_ENCODER_ALGO=sweep / tile2d."""
+    from oracle import c_oracle
+    shp, start, S = pyramid(shapes)
+    L = len(shapes)
+    g = torch.Generator().manual_seed(int(spread_px * 10) + L)
+    value = torch.randn(B, S, 8, 32, generator=g).to(dtype)
+    wh = shp.flip(-1).float()
+    off = torch.randn(B, S, 8, L, 4, 2, generator=g) * spread_px / wh.view(1, 1, 1, L, 1, 2)
+    loc = (_pixel_refs(shapes)[None, :, None, None, None, :] + off).contiguous()
+    attn = torch.softmax(torch.randn(B, S, 8, L * 4, generator=g), -1).view(B, S, 8, L, 4)
+    args = (value.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV), 64)
+    out = rd.ms_deform_attn_forward(*args).float().cpu().numpy()           # encoder entry point if an ALGO is set
+    monkeypatch.delenv("RDETR_MSDA_ENCODER_ALGO", raising=False)
+    direct = rd.ms_deform_attn_forward(*args).float().cpu().numpy()        # shape-agnostic entry point (1-D runs)
+    ref = c_oracle.msda_forward(value.float().numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
+    if dtype == torch.float32:
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out, direct, rtol=0, atol=2e-5)
+    else:
+        assert (np.abs(out - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-3).all()
+        assert (np.abs(out - direct) <= 2.0 ** -7 * np.abs(ref) + 1e-3).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_entry_fused_matches_unfused(rd, dtype, monkeypatch):
+    from oracle import torch_ref
+    shapes = [(30, 50), (15, 25), (8, 13), (4, 7)]
+    shp, start, S = pyramid(shapes)
+    g = torch.Generator().manual_seed(4)
+    B, L = 2, 4
+    value = torch.randn(B, S, 8, 32, generator=g).to(dtype)
+    off = (torch.randn(B, S, 8, L, 4, 2, generator=g) * 3).to(dtype)
+    logits = (torch.randn(B, S, 8, L * 4, generator=g) * 2).to(dtype)
+    ref = _pixel_refs(shapes)[None, :, None, :].expand(B, S, L, 2).contiguous()
+    out = rd.ms_deform_attn_forward_fused(value.to(DEV), shp.to(DEV), start.to(DEV), off.to(DEV), logits.to(DEV), ref.to(DEV))
+    loc = torch_ref.sampling_locations_from_reference(ref, off.float(), shp, 4)
+    w = logits.float().softmax(-1).view(B, S, 8, L, 4)
+    expect = torch_ref.msda_core(value.float(), shp, loc, w)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(out.cpu().numpy(), expect.numpy(), rtol=0, atol=1e-4)
+    else:
+        err = (out.float().cpu() - expect).abs()
+        assert (err <= 2.0 ** -8 * expect.abs() + 1e-3).all(), err.max()

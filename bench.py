@@ -4,23 +4,25 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--queries 900] [--batch 4]
 
 Workload (BASELINE.json configs[1]): relation_detr_resnet50_800_1333 -- padded image 800x1344, 4-level
-pyramid (100,168)(50,84)(25,42)(13,21), S = 22,323 tokens, 8 heads x 32 channels, 4 points,
-batch 4 per GPU, N_q decoder queries (900 = what the reference config runs; 300 via --queries 300).
-One step = one pass of the hot path over one batch of synthetic, HBM-resident inputs:
-    6 x encoder MultiScaleDeformableAttention (N_q = S)            [module: 4 dense projections + HIP core]
-    6 x decoder layer hot ops: RelationSelfAttention (bias + softmax HIP kernel) and
-        MultiScaleDeformableAttention cross-attention (N_q queries)
-    5 x PositionRelationEmbedding (HIP relation-bias kernel)
-(backbone, FFN/LayerNorm and heads are outside the path and not in the step -- stated in
-config.workload).  Random-init weights, synthetic inputs ("data": "synthetic").
+pyramid (100,168)(50,84)(25,42)(13,21), S = 22,323 tokens, 256 channels, 8 heads x 32, 4 points, d_ffn 2048,
+6 encoder + 6 decoder layers, 91 classes, N_q two-stage queries (900 = what the reference config runs;
+BASELINE.json's "300 queries" = detections kept per image, also selectable with --queries 300), batch 4 per GPU.
 
-Multi-GPU: images are independent, so ranks take disjoint image blocks (weak scaling, batch 4 per
-GPU) with no data-path collective; the only exchange is the eval all-gather of the [B,300,6]
-detections over RCCL, done once per step.
+One step = the whole transformer stack on one batch of synthetic, HBM-resident feature pyramids
+(relation_detr_amd/transformer.py: encoder with MSDA self-attention -> two-stage top-k -> decoder with
+relation-biased self-attention + MSDA cross-attention + iterative box refinement -> top-300 detections).
+The backbone and neck are NOT in the step (stock convolutions, out of the hot path -- SURVEY.md section 8d:
+"backbone excluded, stated explicitly"); weights are random-init, inputs synthetic ("data": "synthetic").
+--dtype bf16 converts the network to bfloat16 once (value / output of the MSDA core bf16, fp32 accumulate;
+relation bias and softmax stay fp32); fp32 runs everything in fp32.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel =
-encoder MSDA gather; algorithmic bytes from BASELINE.md section 4 / SURVEY.md section 8d) and
-`cpu_baseline` (the oracle's op-for-op PyTorch restatement on the host cores, bounded sample).
+Multi-GPU: images are independent, so ranks take disjoint image blocks (weak scaling, `--batch` images per GPU)
+with no data-path collective; the only exchange is the eval all-gather of the [B,300,6] detections over RCCL,
+done once per step.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = encoder-shape
+MSDA gather; algorithmic bytes from BASELINE.md section 4 / SURVEY.md section 8d) and `cpu_baseline` (the same
+stack with the oracle's PyTorch-CPU operators on the host cores, bounded sample).
 """
 import argparse
 import json
@@ -44,131 +46,89 @@ def msda_algorithmic_bytes(B, S, Nq, L, P, H, D, value_bytes):
     return B * (touched * value_bytes + Nq * H * L * P * 2 * 4 + Nq * H * L * P * 4 + Nq * H * D * value_bytes)
 
 
-def build_inputs(B, Nq, dev, seed):
+def build_pyramid(B, dev, seed, dtype=torch.float32):
+    """Synthetic multi-level features / masks / position embeddings: N(0,1) features,
+    all-valid masks, N(0,1) position embeddings."""
     g = torch.Generator().manual_seed(seed)
+    feats = [torch.randn(B, 256, h, w, generator=g).to(dev, dtype) for h, w in R50_SHAPES]
+    pos = [torch.randn(B, 256, h, w, generator=g).to(dev, dtype) for h, w in R50_SHAPES]
+    masks = [torch.zeros(B, h, w, dtype=torch.bool, device=dev) for h, w in R50_SHAPES]
+    return feats, masks, pos
+
+
+def build_network(Nq, seed=0, **classes):
+    """Random-init RelationTransformer of the R50 config; fresh MSDA modules have zero offset / attention weights
+    (ms_deform_attn.py:268,279-280), so those get a trained-like spread to make the gather data dependent."""
+    from relation_detr_amd.transformer import build_relation_transformer
+    torch.manual_seed(seed)
+    net = build_relation_transformer(num_classes=91, d_ffn=2048, enc_layers=6, dec_layers=6, num_queries=Nq,
+                                     hybrid_num_proposals=1500, **classes)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, mod in net.named_modules():
+            if hasattr(mod, "sampling_offsets"):
+                mod.sampling_offsets.weight.copy_(torch.randn(mod.sampling_offsets.weight.shape, generator=g) * 0.02)
+                mod.attention_weights.weight.copy_(torch.randn(mod.attention_weights.weight.shape, generator=g) * 0.05)
+    return net.eval()
+
+
+def encoder_kernel_inputs(B, dev, dtype):
+    """Inputs of the dominant kernel at the encoder shape: pixel-centre reference points + N(0, (k/W_l)^2)
+    offsets for point k = 1..4, softmaxed N(0,1) weights (SURVEY.md section 8d / BASELINE.md section 3)."""
+    g = torch.Generator().manual_seed(123)
     shapes = torch.tensor(R50_SHAPES, dtype=torch.int64)
     areas = shapes[:, 0] * shapes[:, 1]
     start = torch.cat([areas.new_zeros(1), areas.cumsum(0)[:-1]])
-    S = int(areas.sum())
-    L = len(R50_SHAPES)
-    # encoder reference points = pixel centres of every level, broadcast over levels (base_transformer.py:57-75)
+    S, L = int(areas.sum()), len(R50_SHAPES)
     refs = []
     for h, w in R50_SHAPES:
         ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
         refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
-    enc_ref = torch.cat(refs, 0)[None, :, None, :].expand(B, S, L, 2).contiguous()
-    dec_ref = torch.cat([torch.rand(B, Nq, 2, generator=g) * 0.8 + 0.1, torch.rand(B, Nq, 2, generator=g) * 0.48 + 0.02], -1)
-    inp = dict(
-        shapes=shapes.to(dev), start=start.to(dev), S=S, L=L,
-        memory=torch.randn(B, S, 256, generator=g).to(dev),
-        pos=torch.randn(B, S, 256, generator=g).to(dev),
-        enc_ref=enc_ref.to(dev),
-        query=torch.randn(B, Nq, 256, generator=g).to(dev),
-        query_pos=torch.randn(B, Nq, 256, generator=g).to(dev),
-        dec_ref=dec_ref[:, :, None, :].expand(B, Nq, L, 4).contiguous().to(dev),
-        boxes=[torch.cat([torch.rand(B, Nq, 2, generator=g), torch.rand(B, Nq, 2, generator=g) * 0.49 + 0.01], -1).to(dev)
-               for _ in range(6)],
-    )
-    return inp
-
-
-def randomise(mod, g):
-    """Fresh MSDA modules have zero offset/attention weights (uniform weights, fixed ring offsets);
-    give them trained-like spread so the gather pattern is data dependent."""
-    with torch.no_grad():
-        mod.sampling_offsets.weight.copy_(torch.randn(mod.sampling_offsets.weight.shape, generator=g) * 0.02)
-        mod.attention_weights.weight.copy_(torch.randn(mod.attention_weights.weight.shape, generator=g) * 0.05)
-    return mod
-
-
-class HotPath(torch.nn.Module):
-    def __init__(self, seed=0):
-        super().__init__()
-        import relation_detr_amd as rd
-        g = torch.Generator().manual_seed(seed)
-        self.enc_attn = torch.nn.ModuleList(randomise(rd.MultiScaleDeformableAttention(256, 4, 8, 4), g) for _ in range(6))
-        self.dec_self = torch.nn.ModuleList(rd.RelationSelfAttention(256, 8) for _ in range(6))
-        self.dec_cross = torch.nn.ModuleList(randomise(rd.MultiScaleDeformableAttention(256, 4, 8, 4), g) for _ in range(6))
-        self.relation = rd.PositionRelationEmbedding(16, 8)
-
-    @torch.no_grad()
-    def forward(self, x):
-        mem = x["memory"]
-        for layer in self.enc_attn:                       # relation_transformer.py:262-269
-            mem = layer(query=mem + x["pos"], reference_points=x["enc_ref"], value=mem, spatial_shapes=x["shapes"],
-                        level_start_index=x["start"], key_padding_mask=None)
-        q = x["query"]
-        rel = None
-        for i in range(6):                                # relation_transformer.py:452-471, 369-374
-            qp = q + x["query_pos"]
-            q = self.dec_self[i](query=qp, key=qp, value=q, attn_mask=rel, need_weights=False)[0]
-            q = self.dec_cross[i](query=q + x["query_pos"], reference_points=x["dec_ref"], value=mem,
-                                  spatial_shapes=x["shapes"], level_start_index=x["start"], key_padding_mask=None)
-            if i < 5:
-                rel = self.relation(x["boxes"][i], x["boxes"][i + 1]).flatten(0, 1)
-        return q
-
-
-def time_encoder_kernel(x, B, dtype, reps=20):
-    """Average duration of the dominant kernel (encoder-shape MSDA gather) from device events on the
-    launch stream, with pixel-centre + N(0, (k/W)^2) offsets."""
-    import relation_detr_amd as rd
-    dev = x["memory"].device
-    S, L = x["S"], x["L"]
-    g = torch.Generator().manual_seed(123)
+    ref = torch.cat(refs, 0)
     value = torch.randn(B, S, 8, 32, generator=g).to(dev).to(dtype)
-    wh = x["shapes"].flip(-1).float().cpu()
+    wh = shapes.flip(-1).float()
     k = torch.arange(1, 5, dtype=torch.float32).view(1, 1, 1, 1, 4, 1)
     off = torch.randn(B, S, 8, L, 4, 2, generator=g) * k / wh.view(1, 1, 1, L, 1, 2)
     off = off * float(os.environ.get("RDETR_BENCH_SPREAD", "1.0"))      # diagnostic knob, default = SURVEY 8d
-    loc = (x["enc_ref"].cpu()[:, :, None, :, None, :] + off).contiguous().to(dev)
+    loc = (ref[None, :, None, None, None, :] + off).contiguous().to(dev)
     attn = torch.softmax(torch.randn(B, S, 8, L * 4, generator=g), -1).view(B, S, 8, L, 4).contiguous().to(dev)
+    return value, shapes.to(dev), start.to(dev), loc, attn, S, L
+
+
+def time_encoder_kernel(B, dev, dtype, reps=20):
+    """Average duration of the dominant kernel from device events recorded on the stream it is launched on."""
+    import relation_detr_amd as rd
+    value, shapes, start, loc, attn, S, L = encoder_kernel_inputs(B, dev, dtype)
     for _ in range(3):
-        rd.ms_deform_attn_forward(value, x["shapes"], x["start"], loc, attn, 64)
+        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        rd.ms_deform_attn_forward(value, x["shapes"], x["start"], loc, attn, 64)
+        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3
+    return e0.elapsed_time(e1) / reps * 1e-3, S, L
 
 
 def cpu_baseline(Nq, budget_s=25.0):
-    """The oracle's op-for-op PyTorch restatement of the same step on the host cores, ONE image
-    (B=1), repeated until ~budget_s of CPU work; returns images/s."""
-    from oracle import torch_ref
-    # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share; more threads than
-    # that oversubscribe (measured: 62 s/image with 256 threads)
+    """The same transformer stack with the oracle's PyTorch-CPU operators (per-level grid_sample + stack + weighted
+    sum, materialised relation embedding, softmax attention) on the host cores: ONE image per pass, repeated until
+    ~budget_s of CPU work; returns images/s."""
+    from oracle.cpu_modules import OracleMSDA, OracleRelation, OracleSelfAttention
+    from relation_detr_amd.transformer import select_detections
+    # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share; more threads than that
+    # oversubscribe (measured: 62 s/image with 256 threads)
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("RDETR_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
-    x = build_inputs(1, Nq, "cpu", 7)
-    g = torch.Generator().manual_seed(0)
-    import relation_detr_amd as rd
-    net = HotPath(0)
-    sd = {k: v for k, v in net.state_dict().items()}
-
-    def msda(prefix, query, ref, value):
-        params = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-        return torch_ref.msda_module_forward(params, query, ref, value, x["shapes"], x["start"], None)
+    net = build_network(Nq, 0, msda_cls=OracleMSDA, self_attn_cls=OracleSelfAttention, relation_cls=OracleRelation)
+    feats, masks, pos = build_pyramid(1, "cpu", 7)
+    sizes = torch.tensor([[800, 1333]])
 
     def one_image():
         with torch.no_grad():
-            mem = x["memory"]
-            for i in range(6):
-                mem = msda(f"enc_attn.{i}.", mem + x["pos"], x["enc_ref"], mem)
-            q, rel = x["query"], None
-            for i in range(6):
-                qp = q + x["query_pos"]
-                p = f"dec_self.{i}."
-                q = torch_ref.self_attn_with_bias(qp, qp, q, sd[p + "in_proj_weight"], sd[p + "in_proj_bias"],
-                                                  sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], rel)
-                q = msda(f"dec_cross.{i}.", q + x["query_pos"], x["dec_ref"], mem)
-                if i < 5:
-                    rel = torch_ref.relation_bias(x["boxes"][i], x["boxes"][i + 1], sd["relation.pos_proj.0.weight"],
-                                                  sd["relation.pos_proj.0.bias"]).flatten(0, 1)
-            return q
+            classes, coords, _, _ = net(feats, masks, pos)
+            return select_detections(classes[-1], coords[-1], sizes)
 
     one_image()                                             # warm
     n, t0 = 0, time.perf_counter()
@@ -179,8 +139,8 @@ def cpu_baseline(Nq, budget_s=25.0):
         if el > budget_s or n >= 16:
             break
     return {"value": n / el, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x 1 image (B=1) of the same step, torch {torch.__version__} CPU kernels, fp32, "
-                      f"{cores} threads, oracle/torch_ref.py (per-level grid_sample + stack + weighted sum)"}
+            "sample": f"{n} x 1 image (B=1) of the same enc+dec stack, torch {torch.__version__} CPU kernels, fp32, "
+                      f"{cores} threads, hot ops = oracle/torch_ref.py (reference fallback path, op for op)"}
 
 
 def main():
@@ -206,21 +166,23 @@ def main():
 
     from relation_detr_amd import _lib
     from relation_detr_amd.dist import gather_detections
-    _lib.load()
+    from relation_detr_amd.transformer import select_detections
+    _lib.load()                                             # fail loudly if the HIP library is missing
 
     B, Nq = args.batch, args.queries
-    x = build_inputs(B, Nq, dev, seed=1000 + rank)          # each rank owns its own image block
-    net = HotPath(0).to(dev).eval()
-    amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16")
-    dets = torch.rand(B, 300, 6, device=dev)                # stand-in [x1,y1,x2,y2,score,label] per image
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    net = build_network(Nq, 0).to(dev).to(dtype)            # same weights on every rank
+    feats, masks, pos = build_pyramid(B, dev, seed=1000 + rank, dtype=dtype)       # each rank owns its image block
+    sizes = torch.tensor([[800, 1333]] * B, device=dev)
     img_ids = torch.arange(B, device=dev) + rank * B
 
+    @torch.no_grad()
     def step():
-        with amp:
-            out = net(x)
+        classes, coords, _, _ = net(feats, masks, pos)
+        dets = select_detections(classes[-1].float(), coords[-1].float(), sizes)
         if world > 1:
             gather_detections(dets, img_ids)                # eval path: one RCCL all-gather per step
-        return out
+        return dets
 
     for _ in range(args.warmup):
         step()
@@ -239,9 +201,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
 
-    kdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    t_kernel = time_encoder_kernel(x, B, kdtype)
-    alg = msda_algorithmic_bytes(B, x["S"], x["S"], x["L"], 4, 8, 32, 2 if args.dtype == "bf16" else 4)
+    t_kernel, S, L = time_encoder_kernel(B, dev, dtype)
+    alg = msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2 if args.dtype == "bf16" else 4)
 
     if rank == 0:
         res = {
@@ -249,12 +210,12 @@ def main():
             "value": world * B * args.steps / el, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"relation_detr_resnet50_800_1333 hot path: 6x encoder MSDA module (S=22323) + "
-                                   f"6x decoder [self-attn with relation bias + MSDA cross-attn] + 5x relation "
-                                   f"embedding; backbone/FFN/LayerNorm/heads excluded",
+            "config": {"workload": "relation_detr_resnet50_800_1333 transformer stack from feature pyramids: 6 encoder "
+                                   "layers (MSDA self-attn, S=22323) + two-stage top-k + 6 decoder layers (relation-biased "
+                                   "self-attn + MSDA cross-attn + box refinement) + top-300 detections; backbone/neck excluded",
                        "batch_per_gpu": B, "global_batch": B * world, "queries": Nq, "levels": 4,
                        "parallelism": f"image-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "msda_fwd_wave_kernel (encoder shape, B=%d)" % B,
+            "roofline": {"bound": "hbm", "kernel": "msda_fwd_qrun_kernel (encoder shape, B=%d)" % B,
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / t_kernel / HBM_PEAK, "traffic": None,
                          "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3},

@@ -14,6 +14,8 @@ Fixtures (see tests/golden/README.md):
   g4_msda_module.npz    nn.Module fwd, 2-d and 4-d reference points, padding mask, state_dict
   g5_relation.npz       box_rel_encoding, sine embed, PositionRelationEmbedding(16, 8)
   g6_self_attn.npz      nn.MultiheadAttention with float relation bias / bool mask / None
+  g7_transformer.npz    RelationTransformer eval forward (2 enc + 3 dec layers, d_ffn 64, 24 queries) on a padded
+                        3-image batch; weights are tests/helpers.py::synthetic_state_dict (not stored)
 """
 import ast
 import os
@@ -196,6 +198,34 @@ def main():
                         in_proj_bias=mha.in_proj_bias.detach().numpy(),
                         out_proj_weight=mha.out_proj.weight.detach().numpy(),
                         out_proj_bias=mha.out_proj.bias.detach().numpy())
+
+    # ---- G7: whole transformer, eval path ---------------------------------------------------------
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from helpers import synthetic_state_dict
+    nlev, nq = 4, 24
+    enc = R.RelationTransformerEncoder(R.RelationTransformerEncoderLayer(256, 64, 0.0, 8, torch.nn.ReLU(inplace=True), nlev, 4), 2)
+    dec = R.RelationTransformerDecoder(R.RelationTransformerDecoderLayer(256, 64, 8, 0.0, torch.nn.ReLU(inplace=True), nlev, 4), 3, 11)
+    tr = R.RelationTransformer(enc, dec, 11, nlev, nq, 30).eval()
+    tr.load_state_dict(synthetic_state_dict(tr.state_dict()))
+    Bt = 3
+    feats = [torch.randn(Bt, 256, h, w, generator=g) for h, w in shapes.tolist()]
+    pos = [torch.randn(Bt, 256, h, w, generator=g) * 0.5 for h, w in shapes.tolist()]
+    masks = []
+    for h, w in shapes.tolist():                                   # image 1 padded right, image 2 padded bottom+right
+        mk = torch.zeros(Bt, h, w, dtype=torch.bool)
+        mk[1, :, int(round(w * 0.75)):] = True
+        mk[2, int(round(h * 0.6)):, :] = True
+        mk[2, :, int(round(w * 0.9)):] = True
+        masks.append(mk)
+    with torch.no_grad():
+        oc, ob, ec, eb = tr(feats, masks, pos)[:4]
+    np.savez_compressed(os.path.join(OUT, "g7_transformer.npz"), shapes=shapes.numpy(),
+                        **{f"feat{i}": f.numpy() for i, f in enumerate(feats)},
+                        **{f"pos{i}": f.numpy() for i, f in enumerate(pos)},
+                        **{f"mask{i}": f.numpy() for i, f in enumerate(masks)},
+                        param_names=np.array(list(tr.state_dict().keys())),
+                        param_shapes=np.array([";".join(map(str, v.shape)) for v in tr.state_dict().values()]),
+                        out_classes=oc.numpy(), out_coords=ob.numpy(), enc_classes=ec.numpy(), enc_coords=eb.numpy())
 
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

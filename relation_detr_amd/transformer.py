@@ -1,0 +1,317 @@
+"""Transformer-level harness around the hot-path modules -- INFERENCE path.
+
+The callers either side of the hot path, restated so that an image batch can be run end to end from
+multi-level feature pyramids to per-layer class logits / boxes:
+    encoder layer / encoder      models/bricks/relation_transformer.py:162-276
+    decoder layer / decoder      models/bricks/relation_transformer.py:279-478
+    two-stage transformer        models/bricks/relation_transformer.py:16-159, models/bricks/base_transformer.py
+Parameter names follow the reference (`encoder.layers.N.self_attn.*`, `decoder.layers.N.cross_attn.*`,
+`decoder.position_relation_embedding.pos_proj.0.*`, `level_embeds`, `enc_output`, ...), so a reference
+`RelationTransformer.state_dict()` loads with `load_state_dict`.  What is NOT here: the training-only branches
+(denoising queries, the hybrid one-to-many decoder pass) -- `forward` is the eval path
+(relation_transformer.py:59-159 with `self.training == False` and no noised queries).
+
+The three hot-path module classes are injectable (`msda_cls`, `self_attn_cls`, `relation_cls`) so that bench.py can
+time the same glue with the CPU oracle's operators as the host baseline; the defaults are the HIP-backed modules.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+from .ms_deform_attn import MultiScaleDeformableAttention
+from .relation import PositionRelationEmbedding
+from .self_attn import RelationSelfAttention
+
+
+def inverse_sigmoid(x: Tensor, eps: float = 1e-3) -> Tensor:
+    """util/misc.py:31-35."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def sine_pos_embed(pos: Tensor, num_pos_feats: int = 128, temperature: float = 10000.0,
+                   scale: float = 2 * math.pi) -> Tensor:
+    """get_sine_pos_embed with exchange_xy=True (models/bricks/position_encoding.py:115-138):
+    [..., n] -> [..., n*num_pos_feats], first two coordinates swapped (y before x)."""
+    k = torch.arange(num_pos_feats // 2, dtype=torch.float32, device=pos.device)
+    dim_t = temperature ** (k * 2 / num_pos_feats)
+    ang = pos.unsqueeze(-1) * scale / dim_t
+    emb = torch.stack((ang.sin(), ang.cos()), dim=-1).flatten(-2)            # [..., n, F]
+    order = [1, 0] + list(range(2, pos.shape[-1]))
+    return emb[..., order, :].flatten(-2)
+
+
+class MLP(nn.Module):
+    """models/bricks/basic.py:6-24 (ReLU between layers, none after the last)."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, output_dim: int, num_layers: int):
+        super().__init__()
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        for layer in self.layers:
+            nn.init.xavier_uniform_(layer.weight)
+            nn.init.zeros_(layer.bias)
+
+    def forward(self, x: Tensor) -> Tensor:
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i + 1 < self.num_layers:
+                x = F.relu(x)
+        return x
+
+
+class RelationTransformerEncoderLayer(nn.Module):
+    def __init__(self, embed_dim=256, d_ffn=1024, n_heads=8, n_levels=4, n_points=4, msda_cls=MultiScaleDeformableAttention):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.self_attn = msda_cls(embed_dim, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.linear1 = nn.Linear(embed_dim, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        nn.init.xavier_uniform_(self.linear1.weight)
+        nn.init.xavier_uniform_(self.linear2.weight)
+
+    def forward(self, query, query_pos, reference_points, spatial_shapes, level_start_index, key_padding_mask=None):
+        attn = self.self_attn(query=query if query_pos is None else query + query_pos, reference_points=reference_points,
+                              value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                              key_padding_mask=key_padding_mask)
+        query = self.norm1(query + attn)
+        return self.norm2(query + self.linear2(F.relu(self.linear1(query))))
+
+
+class RelationTransformerEncoder(nn.Module):
+    """6 layers, then fuse the input and every layer's output: cat -> Linear -> ReLU -> Linear -> LayerNorm."""
+
+    def __init__(self, layers: Sequence[RelationTransformerEncoderLayer]):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.num_layers = len(self.layers)
+        self.embed_dim = self.layers[0].embed_dim
+        d = self.embed_dim
+        self.memory_fusion = nn.Sequential(nn.Linear((self.num_layers + 1) * d, d), nn.ReLU(inplace=True), nn.Linear(d, d),
+                                           nn.LayerNorm(d))
+
+    def forward(self, query, spatial_shapes, level_start_index, reference_points, query_pos=None, query_key_padding_mask=None):
+        outs = [query]
+        for layer in self.layers:
+            query = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask)
+            outs.append(query)
+        return self.memory_fusion(torch.cat(outs, -1))
+
+
+class RelationTransformerDecoderLayer(nn.Module):
+    def __init__(self, embed_dim=256, d_ffn=1024, n_heads=8, n_levels=4, n_points=4,
+                 msda_cls=MultiScaleDeformableAttention, self_attn_cls=RelationSelfAttention):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, n_heads
+        self.cross_attn = msda_cls(embed_dim, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.self_attn = self_attn_cls(embed_dim, n_heads, dropout=0.0, batch_first=True)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.linear1 = nn.Linear(embed_dim, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, embed_dim)
+        self.norm3 = nn.LayerNorm(embed_dim)
+        nn.init.xavier_uniform_(self.linear1.weight)
+        nn.init.xavier_uniform_(self.linear2.weight)
+
+    def forward(self, query, query_pos, reference_points, value, spatial_shapes, level_start_index, self_attn_mask=None,
+                key_padding_mask=None):
+        qp = query + query_pos
+        query = self.norm2(query + self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask,
+                                                  need_weights=False)[0])
+        cross = self.cross_attn(query=query + query_pos, reference_points=reference_points, value=value,
+                                spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                key_padding_mask=key_padding_mask)
+        query = self.norm1(query + cross)
+        return self.norm3(query + self.linear2(F.relu(self.linear1(query))))
+
+
+class RelationTransformerDecoder(nn.Module):
+    """Iterative box refinement with the position-relation bias between layers (relation_transformer.py:320-383)."""
+
+    def __init__(self, layers: Sequence[RelationTransformerDecoderLayer], num_classes: int,
+                 relation_cls=PositionRelationEmbedding):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.num_layers = len(self.layers)
+        self.embed_dim, self.num_heads = self.layers[0].embed_dim, self.layers[0].num_heads
+        d = self.embed_dim
+        self.ref_point_head = MLP(2 * d, d, d, 2)
+        self.query_scale = MLP(d, d, d, 2)
+        self.class_head = nn.ModuleList(nn.Linear(d, num_classes) for _ in range(self.num_layers))
+        self.bbox_head = nn.ModuleList(MLP(d, d, 4, 3) for _ in range(self.num_layers))
+        self.norm = nn.LayerNorm(d)
+        self.position_relation_embedding = relation_cls(16, self.num_heads)
+        prior = -math.log((1 - 0.01) / 0.01)
+        for head in self.class_head:
+            nn.init.constant_(head.bias, prior)
+        for head in self.bbox_head:
+            nn.init.zeros_(head.layers[-1].weight)
+            nn.init.zeros_(head.layers[-1].bias)
+
+    def forward(self, query, reference_points, value, spatial_shapes, level_start_index, valid_ratios,
+                key_padding_mask=None, attn_mask=None, skip_relation=False):
+        classes: List[Tensor] = []
+        coords: List[Tensor] = []
+        ratio_scale = torch.cat([valid_ratios, valid_ratios], -1)[:, None]          # [B,1,L,4]
+        pos_relation = attn_mask
+        tgt_boxes = None
+        for idx, layer in enumerate(self.layers):
+            ref_in = reference_points.detach()[:, :, None] * ratio_scale            # [B,N,L,4]
+            query_pos = self.ref_point_head(sine_pos_embed(ref_in[:, :, 0, :], self.embed_dim // 2).to(query.dtype))
+            if idx != 0:
+                query_pos = query_pos * self.query_scale(query)
+            query = layer(query=query, query_pos=query_pos, reference_points=ref_in, value=value,
+                          spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                          key_padding_mask=key_padding_mask, self_attn_mask=pos_relation)
+            normed = self.norm(query)
+            out_class = self.class_head[idx](normed)
+            out_coord = (self.bbox_head[idx](normed) + inverse_sigmoid(reference_points)).sigmoid()
+            classes.append(out_class)
+            coords.append(out_coord)
+            if idx == self.num_layers - 1:
+                break
+            if not skip_relation:                     # bias for the NEXT layer's self-attention (:369-374)
+                src_boxes = tgt_boxes if idx >= 1 else reference_points
+                tgt_boxes = out_coord
+                pos_relation = self.position_relation_embedding(src_boxes, tgt_boxes).flatten(0, 1)
+                if attn_mask is not None:
+                    pos_relation.masked_fill_(attn_mask, float("-inf"))
+            reference_points = (self.bbox_head[idx](query) + inverse_sigmoid(reference_points.detach())).sigmoid()
+        return torch.stack(classes), torch.stack(coords)
+
+
+class RelationTransformer(nn.Module):
+    """Two-stage transformer, eval path: pyramids -> (layer class logits [Ld,B,N,C], layer boxes [Ld,B,N,4],
+    encoder top-k class logits [B,N,C], encoder top-k boxes [B,N,4])."""
+
+    def __init__(self, encoder: RelationTransformerEncoder, decoder: RelationTransformerDecoder, num_classes: int,
+                 num_feature_levels: int = 4, two_stage_num_proposals: int = 900, hybrid_num_proposals: int = 900):
+        super().__init__()
+        d = encoder.embed_dim
+        self.embed_dim, self.num_feature_levels = d, num_feature_levels
+        self.two_stage_num_proposals, self.num_classes = two_stage_num_proposals, num_classes
+        self.level_embeds = nn.Parameter(torch.empty(num_feature_levels, d))
+        self.enc_output = nn.Linear(d, d)
+        self.enc_output_norm = nn.LayerNorm(d)
+        self.encoder, self.decoder = encoder, decoder
+        self.tgt_embed = nn.Embedding(two_stage_num_proposals, d)
+        self.encoder_class_head = nn.Linear(d, num_classes)
+        self.encoder_bbox_head = MLP(d, d, 4, 3)
+        # training-only heads of the hybrid branch: kept so that reference checkpoints load strictly
+        self.hybrid_tgt_embed = nn.Embedding(hybrid_num_proposals, d)
+        self.hybrid_class_head = nn.Linear(d, num_classes)
+        self.hybrid_bbox_head = MLP(d, d, 4, 3)
+        nn.init.normal_(self.level_embeds)
+        nn.init.xavier_uniform_(self.enc_output.weight)
+        nn.init.zeros_(self.enc_output.bias)
+        nn.init.normal_(self.tgt_embed.weight)
+        nn.init.normal_(self.hybrid_tgt_embed.weight)
+        prior = -math.log((1 - 0.01) / 0.01)
+        for head in (self.encoder_class_head, self.hybrid_class_head):
+            nn.init.constant_(head.bias, prior)
+        for head in (self.encoder_bbox_head, self.hybrid_bbox_head):
+            nn.init.zeros_(head.layers[-1].weight)
+            nn.init.zeros_(head.layers[-1].bias)
+
+    # ---- pyramid bookkeeping (models/bricks/base_transformer.py:17-81) -------------------------------------
+    @staticmethod
+    def flatten_levels(levels: Sequence[Tensor]) -> Tensor:
+        flat = torch.cat([t.flatten(-2) for t in levels], dim=-1)                   # [B,(C,)S]
+        return flat.transpose(1, 2) if flat.dim() == 3 else flat
+
+    @staticmethod
+    def level_misc(masks: Sequence[Tensor]):
+        shapes = masks[0].new_tensor([m.shape[-2:] for m in masks], dtype=torch.int64)
+        start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        ratios = []
+        for m in masks:
+            _, h, w = m.shape
+            ratios.append(torch.stack([(~m[:, 0, :]).sum(1).float() / w, (~m[:, :, 0]).sum(1).float() / h], -1))
+        return shapes, start, torch.stack(ratios, 1)                                # valid_ratios [B,L,2] (w,h)
+
+    @staticmethod
+    def reference_and_proposals(spatial_shapes: Tensor, valid_ratios: Tensor):
+        full = []
+        for lvl, (h, w) in enumerate(spatial_shapes.tolist()):
+            ys, xs = torch.meshgrid(torch.arange(0.5, h + 0.5, device=valid_ratios.device),
+                                    torch.arange(0.5, w + 0.5, device=valid_ratios.device), indexing="ij")
+            ry = ys.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * h)
+            rx = xs.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * w)
+            full.append(torch.stack((rx, ry), -1))
+        full = torch.cat(full, 1)                                                   # [B,S,2]
+        reference = full[:, :, None] * valid_ratios[:, None]                        # [B,S,L,2]
+        areas = spatial_shapes.prod(-1)
+        level_wh = 0.05 * 2.0 ** torch.arange(spatial_shapes.shape[0], device=full.device, dtype=full.dtype)
+        level_wh = level_wh.repeat_interleave(areas)[None, :, None].expand(full.shape[0], -1, 2)
+        return reference, torch.cat([full, level_wh], -1)
+
+    def encoder_output(self, memory: Tensor, proposals: Tensor, padding_mask: Tensor):
+        valid = ((proposals > 0.01) & (proposals < 0.99)).all(-1, keepdim=True)
+        logit = torch.log(proposals / (1 - proposals))
+        logit = logit.masked_fill(padding_mask.unsqueeze(-1) | ~valid, float("inf"))
+        out = memory * (~padding_mask.unsqueeze(-1)) * valid
+        return self.enc_output_norm(self.enc_output(out)), logit
+
+    def forward(self, multi_level_feats: Sequence[Tensor], multi_level_masks: Sequence[Tensor],
+                multi_level_pos_embeds: Sequence[Tensor]):
+        feat = self.flatten_levels(multi_level_feats)
+        mask = self.flatten_levels(multi_level_masks)
+        pos = self.flatten_levels([p + e.view(1, -1, 1, 1) for p, e in zip(multi_level_pos_embeds, self.level_embeds)])
+        shapes, start, valid_ratios = self.level_misc(multi_level_masks)
+        reference, proposals = self.reference_and_proposals(shapes, valid_ratios)
+
+        memory = self.encoder(query=feat, query_pos=pos, query_key_padding_mask=mask, spatial_shapes=shapes,
+                              level_start_index=start, reference_points=reference)
+
+        out_memory, out_proposals = self.encoder_output(memory, proposals, mask)
+        enc_class = self.encoder_class_head(out_memory)
+        enc_coord = (self.encoder_bbox_head(out_memory) + out_proposals).sigmoid()
+        k = self.two_stage_num_proposals
+        top = torch.topk(enc_class.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
+        enc_class = enc_class.gather(1, top.expand(-1, -1, self.num_classes))
+        enc_coord = enc_coord.gather(1, top.expand(-1, -1, 4))
+
+        target = self.tgt_embed.weight.expand(feat.shape[0], -1, -1)
+        classes, coords = self.decoder(query=target, value=memory, key_padding_mask=mask,
+                                       reference_points=enc_coord.detach(), spatial_shapes=shapes,
+                                       level_start_index=start, valid_ratios=valid_ratios)
+        return classes, coords, enc_class, enc_coord
+
+
+def build_relation_transformer(num_classes=91, embed_dim=256, num_heads=8, d_ffn=2048, num_levels=4, num_points=4,
+                               enc_layers=6, dec_layers=6, num_queries=900, hybrid_num_proposals=1500,
+                               msda_cls=MultiScaleDeformableAttention, self_attn_cls=RelationSelfAttention,
+                               relation_cls=PositionRelationEmbedding) -> RelationTransformer:
+    """configs/relation_detr/relation_detr_resnet50_800_1333.py:46-78 (transformer part)."""
+    enc = RelationTransformerEncoder([
+        RelationTransformerEncoderLayer(embed_dim, d_ffn, num_heads, num_levels, num_points, msda_cls)
+        for _ in range(enc_layers)])
+    dec = RelationTransformerDecoder([
+        RelationTransformerDecoderLayer(embed_dim, d_ffn, num_heads, num_levels, num_points, msda_cls, self_attn_cls)
+        for _ in range(dec_layers)], num_classes, relation_cls)
+    return RelationTransformer(enc, dec, num_classes, num_levels, num_queries, hybrid_num_proposals)
+
+
+@torch.no_grad()
+def select_detections(logits: Tensor, boxes: Tensor, image_sizes: Tensor, k: int = 300) -> Tensor:
+    """Fixed-shape form of PostProcess (models/bricks/post_process.py:21-44, default config: 300 detections,
+    no NMS / score filter): sigmoid -> top-k over N*C -> cxcywh to xyxy -> scale to pixels.
+    logits [B,N,C], boxes [B,N,4] cxcywh in [0,1], image_sizes [B,2] (h,w) -> [B,k,6] = (x1,y1,x2,y2,score,label),
+    the tensor `dist.gather_detections` all-gathers."""
+    B, N, C = logits.shape
+    score, idx = torch.topk(logits.sigmoid().view(B, -1), k, dim=1)
+    box_idx = torch.div(idx, C, rounding_mode="trunc")
+    label = idx % C
+    cx, cy, w, h = boxes.gather(1, box_idx.unsqueeze(-1).expand(-1, -1, 4)).unbind(-1)
+    xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+    img_h, img_w = image_sizes.to(xyxy.dtype).unbind(1)
+    xyxy = xyxy * torch.stack([img_w, img_h, img_w, img_h], 1)[:, None, :]
+    return torch.cat([xyxy, score.unsqueeze(-1).to(xyxy.dtype), label.unsqueeze(-1).to(xyxy.dtype)], -1)

@@ -31,3 +31,28 @@ def make_msda_inputs(B, Nq, shapes, H=8, D=32, P=4, seed=0, spread=0.15, dtype=t
     loc = torch.rand(B, Nq, H, L, P, 2, generator=g) * (1 + 2 * spread) - spread
     attn = torch.softmax(torch.randn(B, Nq, H, L * P, generator=g), -1).view(B, Nq, H, L, P)
     return value, shapes_t, start, loc, attn
+
+
+def synthetic_state_dict(reference_state_dict):
+    """Deterministic, RNG-free parameter values for a transformer state_dict (name -> tensor), so that the
+    reference model (in oracle/gen_golden.py) and the harness under test can be loaded with IDENTICAL weights
+    without committing tens of MB of tensors: value = f(parameter name, flat index)."""
+    import zlib
+    out = {}
+    for name, ref in reference_state_dict.items():
+        n = ref.numel()
+        idx = np.arange(n, dtype=np.float64)
+        phase = (zlib.crc32(name.encode()) % 1000) / 1000.0 * 6.283185307179586
+        if "norm" in name and name.endswith("weight"):
+            v = 1.0 + 0.1 * np.sin(idx * 0.37 + phase)
+        elif name.endswith("sampling_offsets.bias"):
+            v = 2.0 * np.sin(idx * 0.77 + phase)                                  # offsets of a few pixels
+        elif name.endswith("bias"):
+            v = 0.05 * np.sin(idx * 0.91 + phase)
+        elif ref.dim() >= 2 and "embed" not in name:
+            fan_in = int(np.prod(ref.shape[1:]))
+            v = np.sin(idx * 0.7071 + phase) * np.sqrt(3.0 / fan_in)
+        else:                                                                      # embeddings, level_embeds
+            v = 0.7 * np.sin(idx * 0.613 + phase)
+        out[name] = torch.from_numpy(v.astype(np.float32)).reshape(ref.shape)
+    return out

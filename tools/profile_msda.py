@@ -20,30 +20,29 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     dev = torch.device("cuda", 0)
-    x = bench.build_inputs(B, 900, dev, 1000)
-    t = bench.time_encoder_kernel(x, B, dtype, reps=reps)
-    alg = bench.msda_algorithmic_bytes(B, x["S"], x["S"], x["L"], 4, 8, 32, 2 if dtype == torch.bfloat16 else 4)
+    t, S, L = bench.time_encoder_kernel(B, dev, dtype, reps=reps)
+    alg = bench.msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2 if dtype == torch.bfloat16 else 4)
     print(f"{dtype} B={B}: {t*1e6:.1f} us/launch, algorithmic {alg/1e6:.1f} MB -> {alg/t/1e9:.0f} GB/s ({alg/t/8e12*100:.1f}% of 8 TB/s)")
     # decoder shape: Nq = 900 box queries per image (centre +- U(-.5,.5)*wh)
     import relation_detr_amd as rd
     g = torch.Generator().manual_seed(5)
-    Nq, L = 900, x["L"]
-    value = torch.randn(B, x["S"], 8, 32, generator=g).to(dev).to(dtype)
+    Nq = 900
+    value, shapes, start, _, _, _, _ = bench.encoder_kernel_inputs(B, dev, dtype)
     cxcy = torch.rand(B, Nq, 1, 1, 1, 2, generator=g) * 0.8 + 0.1
     wh = torch.rand(B, Nq, 1, 1, 1, 2, generator=g) * 0.48 + 0.02
     loc = (cxcy + (torch.rand(B, Nq, 8, L, 4, 2, generator=g) - 0.5) * wh).contiguous().to(dev)
     attn = torch.softmax(torch.randn(B, Nq, 8, L * 4, generator=g), -1).view(B, Nq, 8, L, 4).contiguous().to(dev)
     for _ in range(3):
-        rd.ms_deform_attn_forward(value, x["shapes"], x["start"], loc, attn, 64)
+        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        rd.ms_deform_attn_forward(value, x["shapes"], x["start"], loc, attn, 64)
+        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64)
     e1.record()
     torch.cuda.synchronize()
     td = e0.elapsed_time(e1) / reps * 1e-3
-    algd = bench.msda_algorithmic_bytes(B, x["S"], Nq, L, 4, 8, 32, 2 if dtype == torch.bfloat16 else 4)
+    algd = bench.msda_algorithmic_bytes(B, S, Nq, L, 4, 8, 32, 2 if dtype == torch.bfloat16 else 4)
     print(f"   decoder Nq=900: {td*1e6:.1f} us/launch, algorithmic {algd/1e6:.1f} MB -> {algd/td/1e9:.0f} GB/s")
 
 

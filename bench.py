@@ -111,6 +111,18 @@ def time_encoder_kernel(B, dev, dtype, reps=20):
     return e0.elapsed_time(e1) / reps * 1e-3, S, L
 
 
+def pmc_traffic(dtype_name, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
+    tools/profile_msda.py, profiles/r01/pmc_msda_fwd_qrun_B4_encoder.json): (2*FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte requests at 64 B; for this kernel's mix
+    of 16-byte gathers and 4/8-byte streams the factor is an upper bound, the raw sum is the lower bound)."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_msda_fwd_qrun_B4_encoder.json")
+    if B != 4 or not os.path.exists(path):
+        return None
+    c = json.load(open(path))["per_launch_mean"].get(dtype_name)
+    return None if not c else (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+
+
 def cpu_baseline(Nq, budget_s=25.0):
     """The same transformer stack with the oracle's PyTorch-CPU operators (per-level grid_sample + stack + weighted
     sum, materialised relation embedding, softmax attention) on the host cores: ONE image per pass, repeated until
@@ -217,7 +229,7 @@ def main():
                        "parallelism": f"image-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_qrun_kernel (encoder shape, B=%d)" % B,
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": alg / t_kernel / HBM_PEAK, "traffic": None,
+                         "frac": alg / t_kernel / HBM_PEAK, "traffic": pmc_traffic(args.dtype, B),
                          "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:

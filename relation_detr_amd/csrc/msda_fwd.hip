@@ -130,8 +130,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const int LP = L * kPoints;
 
     __shared__ LevelTable lvl;
-    __shared__ u32x4 stage_off[kWavesPerBlock][kMaxLevels * kPoints * kSlots];
-    __shared__ f32x4 stage_wgt[kWavesPerBlock][kMaxLevels * kPoints * kSlots];
+    constexpr int kStageLevels = LT ? LT : kMaxLevels;      // LDS per block: 16 KiB (fp32) / 32 KiB (bf16) at L = 4
+    __shared__ u32x4 stage_off[kWavesPerBlock][kStageLevels * kPoints * kSlots];
+    __shared__ f32x4 stage_wgt[kWavesPerBlock][kStageLevels * kPoints * kSlots];
 
     const int tid = threadIdx.x;
     if (tid < L) {

@@ -82,31 +82,34 @@ int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_
                                   const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B, int S,
                                   int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
 
-/* Encoder-shape MSDA (self-attention over the pyramid: the Nq == S queries ARE the pyramid's pixels, in the
- * level-packed raster order of `value`; relation_transformer.py:262-269 with base_transformer.py:57-75 reference
- * points).  Same arithmetic and results as rdetr_msda_forward_* / rdetr_msda_forward_fused_*; knowing that queries
- * are pixels allows launch geometries that exploit spatial locality.  H = 8, D = 32, P = 4 are implied; L <= 8;
- * `host_spatial_shapes` is a HOST copy of the [L,2] (h,w) table (the launch geometry depends on it), levels packed
- * contiguously (level_start = running sum).  Correct for ANY sampling locations.
- * Environment RDETR_MSDA_ENCODER_ALGO: "tile2d" (2-D patch per workgroup) or "sweep" (LDS sweep kernel,
- * csrc/msda_sweep.hip) -- both experimental and, as measured in round 1, not faster than the default, which is the
- * same 1-D query-run launch rdetr_msda_forward_* uses. */
-int rdetr_msda_encoder_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+/* "Planned" forms of the four entry points above (H = 8, D = 32, P = 4 implied; L <= 8): identical
+ * arithmetic and results, plus `host_spatial_shapes`, a HOST copy of the [L,2] (h,w) table, so that the launch can
+ * be planned around the pyramid geometry (levels packed contiguously, level_start = running sum).  The reference
+ * operator reads the table on the device only (ms_deform_im2col_cuda.cuh:263-267); callers that already hold it on
+ * the host (relation_detr_amd/ops.py caches one copy per pyramid) should prefer these.
+ * Strategy, environment RDETR_MSDA_ALGO (read once; DESIGN.md section 4.2 has the measurements):
+ *   "qrun" (default)  the direct query-run kernel of rdetr_msda_forward_* -- the fastest of the four in round 1;
+ *   "hybrid"          csrc/msda_hybrid.hip when L == 4 and Nq >= 1024: the planes of the coarsest levels are kept
+ *                     in LDS and gathered from there, the fine levels by range-checked global loads;
+ *   "tile2d", "sweep" strategies for Nq == S (queries = the pyramid's pixels): 2-D patch per workgroup / LDS band
+ *                     kernel (csrc/msda_sweep.hip).
+ * The alternatives are experimental: parity-tested, not faster. */
+int rdetr_msda_forward_planned_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
                                    const int64_t *host_spatial_shapes, const float *sampling_loc,
-                                   const float *attn_weight, int B, int S, int L, float *out, void *stream);
-int rdetr_msda_encoder_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                   const float *attn_weight, int B, int S, int L, int Nq, float *out, void *stream);
+int rdetr_msda_forward_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                                     const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                    const float *sampling_loc, const float *attn_weight, int B, int S, int L,
+                                    const float *sampling_loc, const float *attn_weight, int B, int S, int L, int Nq,
                                     uint16_t *out, void *stream);
-int rdetr_msda_encoder_forward_fused_f32(const float *value, const int64_t *spatial_shapes,
+int rdetr_msda_forward_fused_planned_f32(const float *value, const int64_t *spatial_shapes,
                                          const int64_t *level_start_index, const int64_t *host_spatial_shapes,
                                          const float *sampling_offsets, const float *attn_logits,
-                                         const float *reference_points, int ref_dim, int B, int S, int L, float *out,
-                                         void *stream);
-int rdetr_msda_encoder_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                         const float *reference_points, int ref_dim, int B, int S, int L, int Nq,
+                                         float *out, void *stream);
+int rdetr_msda_forward_fused_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                                           const int64_t *level_start_index, const int64_t *host_spatial_shapes,
                                           const uint16_t *sampling_offsets, const uint16_t *attn_logits,
-                                          const float *reference_points, int ref_dim, int B, int S, int L,
+                                          const float *reference_points, int ref_dim, int B, int S, int L, int Nq,
                                           uint16_t *out, void *stream);
 
 /* 1 if (H, D, L, P) is served by the query-run kernel, 0 if by the generic kernel. */

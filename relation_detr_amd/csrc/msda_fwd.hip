@@ -450,71 +450,85 @@ extern "C" int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Encoder-shape entry points (Nq == S, host copy of the shape table available).  Two experimental launch
-// strategies were built and measured in round 1, selected by RDETR_MSDA_ENCODER_ALGO:
-//   "tile2d" -- query-run kernel, each workgroup = a (8|16)-wide x 4-row patch of one level;
-//   "sweep"  -- LDS sweep kernel (csrc/msda_sweep.hip);
-// anything else (default) = the plain 1-D query-run launch, which was the fastest of the three.
+// "Planned" entry points: same operators, plus a HOST copy of the shape table so that the launch can be planned
+// around the pyramid geometry.  RDETR_MSDA_ALGO selects the strategy (read once):
+//   qrun (default) -- the direct query-run kernel (the fastest of the four in round 1);
+//   hybrid         -- csrc/msda_hybrid.hip: planes of the coarsest levels resident in LDS (L == 4, Nq >= 1024);
+//   tile2d, sweep  -- encoder-shape (Nq == S) strategies: 2-D patch launch / LDS band kernel (csrc/msda_sweep.hip).
+// The three alternatives are experimental: correct (parity-tested) but not faster.
 namespace rdetr {
 template <typename T, bool FUSED>
 int msda_sweep_forward(const T *value, const int64_t *host_shapes, const void *src_a, const void *src_b, const float *ref,
                        int ref_dim, int B, int S, int L, T *out, hipStream_t stream);
+template <typename T, bool FUSED>
+int msda_hybrid_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const int64_t *host_shapes,
+                        const void *src_a, const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq,
+                        T *out, hipStream_t stream);
 
 template <typename T, bool FUSED>
-static int msda_encoder(const T *value, const int64_t *shapes, const int64_t *level_start, const int64_t *host_shapes,
-                        const void *src_a, const void *src_b, const float *ref, int ref_dim, int B, int S, int L, T *out,
-                        hipStream_t stream)
+static int msda_planned(const T *value, const int64_t *shapes, const int64_t *level_start, const int64_t *host_shapes,
+                        const void *src_a, const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq,
+                        T *out, hipStream_t stream)
 {
     if (!host_shapes) return RDETR_ERR_INVALID_ARG;
+    if (B < 0 || S < 0 || Nq < 0 || L <= 0) return RDETR_ERR_INVALID_ARG;
     static const char algo = []() {
-        const char *e = getenv("RDETR_MSDA_ENCODER_ALGO");
+        const char *e = getenv("RDETR_MSDA_ALGO");
         return e ? e[0] : 'q';
     }();
-    if (algo == 's') {
-        const int st = msda_sweep_forward<T, FUSED>(value, host_shapes, src_a, src_b, ref, ref_dim, B, S, L, out, stream);
-        if (st != RDETR_ERR_UNSUPPORTED) return st;
+    if (B > 0 && Nq > 0 && S > 0 && value && src_a && src_b && out && (!FUSED || ref)) {
+        if (algo == 's' && Nq == S) {
+            const int st = msda_sweep_forward<T, FUSED>(value, host_shapes, src_a, src_b, ref, ref_dim, B, S, L, out, stream);
+            if (st != RDETR_ERR_UNSUPPORTED) return st;
+        }
+        if (algo == 'h') {
+            const int st = msda_hybrid_forward<T, FUSED>(value, shapes, level_start, host_shapes, src_a, src_b, ref, ref_dim,
+                                                         B, S, L, Nq, out, stream);
+            if (st != RDETR_ERR_UNSUPPORTED) return st;
+        }
     }
-    return msda_forward<T, FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, kHeads, kHeadDim, L, S,
-                                  kPoints, out, stream, algo == 't' ? host_shapes : nullptr);
+    return msda_forward<T, FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, kHeads, kHeadDim, L, Nq,
+                                  kPoints, out, stream, (algo == 't' && Nq == S) ? host_shapes : nullptr);
 }
 }  // namespace rdetr
 
-extern "C" int rdetr_msda_encoder_forward_f32(const float *value, const int64_t *spatial_shapes,
+extern "C" int rdetr_msda_forward_planned_f32(const float *value, const int64_t *spatial_shapes,
                                               const int64_t *level_start_index, const int64_t *host_spatial_shapes,
                                               const float *sampling_loc, const float *attn_weight, int B, int S, int L,
-                                              float *out, void *stream)
+                                              int Nq, float *out, void *stream)
 {
-    return rdetr::msda_encoder<float, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
-                                             attn_weight, nullptr, 0, B, S, L, out, static_cast<hipStream_t>(stream));
+    return rdetr::msda_planned<float, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
+                                             attn_weight, nullptr, 0, B, S, L, Nq, out, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int rdetr_msda_encoder_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+extern "C" int rdetr_msda_forward_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                                                const int64_t *level_start_index, const int64_t *host_spatial_shapes,
                                                const float *sampling_loc, const float *attn_weight, int B, int S, int L,
-                                               uint16_t *out, void *stream)
+                                               int Nq, uint16_t *out, void *stream)
 {
-    return rdetr::msda_encoder<uint16_t, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
-                                                attn_weight, nullptr, 0, B, S, L, out, static_cast<hipStream_t>(stream));
+    return rdetr::msda_planned<uint16_t, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
+                                                attn_weight, nullptr, 0, B, S, L, Nq, out,
+                                                static_cast<hipStream_t>(stream));
 }
 
-extern "C" int rdetr_msda_encoder_forward_fused_f32(const float *value, const int64_t *spatial_shapes,
+extern "C" int rdetr_msda_forward_fused_planned_f32(const float *value, const int64_t *spatial_shapes,
                                                     const int64_t *level_start_index, const int64_t *host_spatial_shapes,
                                                     const float *sampling_offsets, const float *attn_logits,
                                                     const float *reference_points, int ref_dim, int B, int S, int L,
-                                                    float *out, void *stream)
+                                                    int Nq, float *out, void *stream)
 {
-    return rdetr::msda_encoder<float, true>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_offsets,
-                                            attn_logits, reference_points, ref_dim, B, S, L, out,
+    return rdetr::msda_planned<float, true>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_offsets,
+                                            attn_logits, reference_points, ref_dim, B, S, L, Nq, out,
                                             static_cast<hipStream_t>(stream));
 }
 
-extern "C" int rdetr_msda_encoder_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+extern "C" int rdetr_msda_forward_fused_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
                                                      const int64_t *level_start_index, const int64_t *host_spatial_shapes,
                                                      const uint16_t *sampling_offsets, const uint16_t *attn_logits,
                                                      const float *reference_points, int ref_dim, int B, int S, int L,
-                                                     uint16_t *out, void *stream)
+                                                     int Nq, uint16_t *out, void *stream)
 {
-    return rdetr::msda_encoder<uint16_t, true>(value, spatial_shapes, level_start_index, host_spatial_shapes,
-                                               sampling_offsets, attn_logits, reference_points, ref_dim, B, S, L, out,
+    return rdetr::msda_planned<uint16_t, true>(value, spatial_shapes, level_start_index, host_spatial_shapes,
+                                               sampling_offsets, attn_logits, reference_points, ref_dim, B, S, L, Nq, out,
                                                static_cast<hipStream_t>(stream));
 }

@@ -73,12 +73,12 @@ def check_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, 
                 f"level (h={h}, w={w}, start={s}) does not fit a value tensor with {num_value} positions")
 
 
-def _encoder_shape(spatial_shapes, level_start_index, B, S, H, D, L, Nq, P):
-    """Host copy of the [L,2] shape table (as a ctypes array) when the call has the encoder shape the LDS sweep
-    kernel serves -- Nq == S, levels packed contiguously, H = 8, D = 32, P = 4 -- else None.
-    The encoder entry points only pay off with one of the experimental launch strategies
-    (RDETR_MSDA_ENCODER_ALGO=tile2d|sweep); without that variable the plain entry point is used."""
-    if Nq != S or (H, D, P) != (8, 32, 4) or L > 8 or os.environ.get("RDETR_MSDA_ENCODER_ALGO", "") not in ("tile2d", "sweep"):
+def _host_shape_table(spatial_shapes, level_start_index, S, H, D, L, P):
+    """Host copy of the [L,2] shape table as a ctypes int64 array when the planned entry points apply -- H = 8,
+    D = 32, P = 4, L <= 8, levels packed contiguously and covering the value tensor -- else None.
+    The planned entry points only differ from the plain ones when an experimental strategy is selected
+    (RDETR_MSDA_ALGO=hybrid|tile2d|sweep), so without that variable the plain entry points are used."""
+    if (H, D, P) != (8, 32, 4) or L > 8 or os.environ.get("RDETR_MSDA_ALGO", "qrun") not in ("hybrid", "tile2d", "sweep"):
         return None
     shapes, starts = host_levels(spatial_shapes, level_start_index)
     run = 0
@@ -118,14 +118,13 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
         fn = lib.rdetr_msda_forward_bf16
     else:
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
-    host = _encoder_shape(spatial_shapes, level_start_index, B, S, H, D, L, Nq, P)
-    if host is not None:            # encoder self-attention with an experimental launch strategy selected
-        enc = lib.rdetr_msda_encoder_forward_f32 if value.dtype == torch.float32 else lib.rdetr_msda_encoder_forward_bf16
-        st = enc(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), host,
-                 sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, L, out.data_ptr(), _stream_ptr(value))
-        if st != -2:                # -2 = shape not served by the sweep kernel -> direct kernel below
-            _lib.check(st, "rdetr_msda_encoder_forward")
-            return out
+    host = _host_shape_table(spatial_shapes, level_start_index, S, H, D, L, P)
+    if host is not None:            # launch planned around the pyramid geometry (hybrid LDS / direct kernel)
+        planned = lib.rdetr_msda_forward_planned_f32 if value.dtype == torch.float32 else lib.rdetr_msda_forward_planned_bf16
+        st = planned(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), host,
+                     sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, L, Nq, out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_planned")
+        return out
     st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
     _lib.check(st, "rdetr_msda_forward")
@@ -164,16 +163,15 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
     else:
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
-    host = _encoder_shape(spatial_shapes, level_start_index, B, S, H, D, L, Nq, P)
-    if host is not None:            # encoder self-attention with an experimental launch strategy selected
-        enc = (lib.rdetr_msda_encoder_forward_fused_f32 if value.dtype == torch.float32
-               else lib.rdetr_msda_encoder_forward_fused_bf16)
-        st = enc(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), host,
-                 sampling_offsets.data_ptr(), attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, B, S, L,
-                 out.data_ptr(), _stream_ptr(value))
-        if st != -2:
-            _lib.check(st, "rdetr_msda_encoder_forward_fused")
-            return out
+    host = _host_shape_table(spatial_shapes, level_start_index, S, H, D, L, P)
+    if host is not None:            # launch planned around the pyramid geometry (hybrid LDS / direct kernel)
+        planned = (lib.rdetr_msda_forward_fused_planned_f32 if value.dtype == torch.float32
+                   else lib.rdetr_msda_forward_fused_planned_bf16)
+        st = planned(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), host,
+                     sampling_offsets.data_ptr(), attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, B, S, L,
+                     Nq, out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_fused_planned")
+        return out
     st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
             attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, B, S, H, D, L, Nq, P, out.data_ptr(),
             _stream_ptr(value))

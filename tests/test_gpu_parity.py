@@ -387,9 +387,10 @@ def _pixel_refs(shapes):
     ([(64, 96), (32, 48), (16, 24), (8, 12)], 2, 4.0, torch.bfloat16),
 ])
 def test_encoder_entry_matches_oracle_and_plain_entry(rd, shapes, B, spread_px, dtype, monkeypatch):
-    """Nq == S (encoder self-attention) goes through rdetr_msda_encoder_forward_*; it must agree with the oracle
-    and, to rounding, with the shape-agnostic entry point, whatever the offsets.  tests/test_gpu_sweep.py
-    repeats this file's encoder cases in child processes with RDETR_MSDA_ENCODER_ALGO=sweep / tile2d."""
+    """Encoder-shape calls (Nq == S): the Python op (which goes through rdetr_msda_forward_planned_* when
+    RDETR_MSDA_ALGO selects an experimental strategy) must agree with the oracle and, to rounding, with the
+    reference-equivalent C entry point, whatever the offsets.  tests/test_gpu_sweep.py repeats this file's encoder
+    cases in child processes with RDETR_MSDA_ALGO=sweep / tile2d / hybrid."""
     from oracle import c_oracle
     shp, start, S = pyramid(shapes)
     L = len(shapes)
@@ -400,9 +401,13 @@ def test_encoder_entry_matches_oracle_and_plain_entry(rd, shapes, B, spread_px, 
     loc = (_pixel_refs(shapes)[None, :, None, None, None, :] + off).contiguous()
     attn = torch.softmax(torch.randn(B, S, 8, L * 4, generator=g), -1).view(B, S, 8, L, 4)
     args = (value.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV), 64)
-    out = rd.ms_deform_attn_forward(*args).float().cpu().numpy()           # encoder entry point if an ALGO is set
-    monkeypatch.delenv("RDETR_MSDA_ENCODER_ALGO", raising=False)
-    direct = rd.ms_deform_attn_forward(*args).float().cpu().numpy()        # shape-agnostic entry point (1-D runs)
+    out = rd.ms_deform_attn_forward(*args).float().cpu().numpy()           # planned entry point (RDETR_MSDA_ALGO)
+    lib = rd._lib.load()                                                   # reference-equivalent entry point (direct kernel)
+    direct_t = torch.empty(B, S, 256, dtype=dtype, device=DEV)
+    fn = lib.rdetr_msda_forward_f32 if dtype == torch.float32 else lib.rdetr_msda_forward_bf16
+    assert fn(args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(), args[3].data_ptr(), args[4].data_ptr(), B, S, 8, 32,
+              L, S, 4, direct_t.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    direct = direct_t.float().cpu().numpy()
     ref = c_oracle.msda_forward(value.float().numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
     if dtype == torch.float32:
         np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)

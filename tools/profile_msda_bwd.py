@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Time the MSDA backward kernel (fp32) at the encoder shape (B images, S = Nq = 22,323) and the decoder shape."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+import relation_detr_amd as rd
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+dev = torch.device("cuda", 0)
+value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(B, dev, torch.float32)
+go = torch.randn(B, S, 256, device=dev)
+for _ in range(2):
+    rd.ms_deform_attn_backward(value, shapes, start, loc, attn, go, 64)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    rd.ms_deform_attn_backward(value, shapes, start, loc, attn, go, 64)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 5 * 1e-3
+atomic_bytes = B * S * 8 * L * 4 * 4 * 32 * 4
+print(f"backward encoder shape B={B}: {t*1e3:.2f} ms (includes the grad_value zero-fill), atomic bytes {atomic_bytes/1e9:.2f} GB "
+      f"-> {atomic_bytes/t/1e12:.2f} TB/s of float atomics (chip-wide rate ~1.3 TB/s)")

@@ -28,7 +28,7 @@ def image_block(num_images: int, rank: int, world_size: int) -> Tuple[int, int]:
 def gather_detections(dets: torch.Tensor, image_ids: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather ``dets [B_local, K, 6]`` and ``image_ids [B_local]`` from every rank (equal
     B_local on all ranks) -> ``([world*B_local, K, 6], [world*B_local])`` ordered by rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return dets, image_ids
     world = dist.get_world_size(group)
     dets = dets.contiguous()

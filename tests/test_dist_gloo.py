@@ -56,3 +56,23 @@ def test_gather_is_identity_without_process_group():
     d, i = torch.zeros(2, 300, 6), torch.arange(2)
     out_d, out_i = gather_detections(d, i)
     assert out_d is d and out_i is i
+
+
+@pytest.mark.gpu
+def test_gather_detections_rccl_single_rank():
+    """The RCCL code path (all_gather_into_tensor on device tensors) with a one-rank process group: the 8-GPU run
+    belongs to the driver, this at least executes the same calls on the GPU box."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        d = torch.rand(4, 300, 6, device="cuda:0")
+        i = torch.arange(4, device="cuda:0")
+        out_d, out_i = gather_detections(d, i)
+        torch.cuda.synchronize()
+        assert out_d.shape == (4, 300, 6) and torch.equal(out_d, d) and torch.equal(out_i, i)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

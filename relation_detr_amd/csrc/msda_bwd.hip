@@ -6,12 +6,11 @@
 // (b,q,head), 4 atomicAdd per thread per point, thread 0 serially sums 32 partials for the
 // location / weight gradients).
 //
-// Same wave-per-query decomposition as the forward kernel (msda_fwd.hip): lane = head*8 + sub owns
-// 4 channels.  Per point the lane re-gathers the 4 corners (needed for d/dloc and d/dweight),
-// scatters w_corner * g * attn into grad_value with hardware fp32 atomics (each wave instruction
-// adds eight 128-byte head rows; out-of-level corners carry offset 0x80000000 and are dropped by
-// the buffer range check), and the per-head sums over D = 32 channels for grad_loc / grad_attn
-// are an 8-lane xor-shuffle reduction instead of a shared-memory pass.
+// One wavefront owns one head and two consecutive queries, one channel per lane: the 4 corner rows are re-gathered
+// (needed for d/dloc and d/dweight), `w_corner * g * attn` is scattered into grad_value with hardware fp32 atomics
+// whose wave instruction covers two full 128-byte head rows (out-of-level corners carry offset 0x80000000 and are
+// dropped by the buffer range check), and the per-head sums over D = 32 channels for grad_loc / grad_attn are
+// 32-lane xor-shuffle reductions instead of a shared-memory pass.
 //
 // Float atomics make grad_value's summation order run-dependent (as in the reference).
 #include "common.h"
@@ -26,24 +25,21 @@ struct BwdLevels {
     int h[kBMaxL], w[kBMaxL], start[kBMaxL];
 };
 
-__device__ __forceinline__ float sum8(float v)
+// sum over the 32 lanes of one (query, head) row (lanes 0-31 / 32-63 reduce independently)
+__device__ __forceinline__ float sum32(float v)
 {
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
     return v;
 }
 
-__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
-__device__ __forceinline__ void atomic_add4(__amdgpu_buffer_rsrc_t rs, unsigned off, f32x4 v)
-{
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.x, rs, off, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.y, rs, off + 4, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.z, rs, off + 8, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v.w, rs, off + 12, 0, 0);
-}
-
+// One wavefront = ONE head x TWO consecutive queries; lane = pair*32 + channel, one channel per lane.
+// Every atomic wave instruction therefore adds two full 128-byte head rows (the access shape that runs at the
+// chip-wide float-atomic rate, MI355X_MICROARCH.md "Global float atomics"; the first version, 4 channels per lane
+// x 8 heads, added 8 x 32 sparse bytes per instruction and reached 0.36 TB/s).
 __global__ __launch_bounds__(kBWaves *kWave) void msda_bwd_wave_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc, const float *__restrict__ attn, const float *__restrict__ grad_out, int S, int L,
@@ -52,10 +48,10 @@ __global__ __launch_bounds__(kBWaves *kWave) void msda_bwd_wave_kernel(
 {
     const int LP = L * kBP;
     __shared__ BwdLevels lvl;
-    // per wave, [point][head]: corner offsets | {hy, hx, ly, lx} | {attn, W_l, H_l, inside}
-    __shared__ u32x4 st_off[kBWaves][kBMaxL * kBP * kBH];
-    __shared__ f32x4 st_frac[kBWaves][kBMaxL * kBP * kBH];
-    __shared__ f32x4 st_misc[kBWaves][kBMaxL * kBP * kBH];
+    // per wave, [point][pair]: corner offsets | {hy, hx, ly, lx} | {attn (0 if outside), W_l, H_l, inside}
+    __shared__ u32x4 st_off[kBWaves][kBMaxL * kBP * 2];
+    __shared__ f32x4 st_frac[kBWaves][kBMaxL * kBP * 2];
+    __shared__ f32x4 st_misc[kBWaves][kBMaxL * kBP * 2];
 
     const int tid = threadIdx.x;
     if (tid < L) {
@@ -65,34 +61,37 @@ __global__ __launch_bounds__(kBWaves *kWave) void msda_bwd_wave_kernel(
     }
     __syncthreads();
 
+    // logical block -> (image b, head m, tile of 2*kBWaves consecutive queries)
     const int logical = xcd_contiguous_block(blockIdx.x, nblk);
-    const int b = logical / tiles_per_image;
-    const int tile = logical - b * tiles_per_image;
+    const int bm = logical / tiles_per_image;
+    const int tile = logical - bm * tiles_per_image;
+    const int b = bm / kBH, m = bm - b * kBH;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, m = lane >> 3, sub = lane & 7;
-    const int q = tile * kBWaves + wave;
-    if (q >= Nq) return;
+    const int lane = tid & 63, pair = lane >> 5, c = lane & 31;
+    const int q = (tile * kBWaves + wave) * 2 + pair;
+    const bool qok = q < Nq;
 
-    const size_t img = (size_t)b * S * (kBH * kBD);
-    const __amdgpu_buffer_rsrc_t rs_v =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value) + img, 0, (unsigned)S * kBPixelBytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_g =
-        __builtin_amdgcn_make_buffer_rsrc(grad_value + img, 0, (unsigned)S * kBPixelBytes, 0x00020000);
-    const unsigned lane_off = (unsigned)m * kBHeadBytes + (unsigned)sub * 16u;
+    const size_t plane = (size_t)b * S * (kBH * kBD) + (size_t)m * kBD;
+    const unsigned nrec = (unsigned)S * kBPixelBytes - (unsigned)m * kBHeadBytes;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value) + plane, 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(grad_value + plane, 0, nrec, 0x00020000);
+    const unsigned lane_off = (unsigned)c * 4u;
 
-    const size_t row = (size_t)b * Nq + q;
+    const size_t row = (size_t)b * Nq + (qok ? q : 0);
     const size_t hrow = (row * kBH + m) * (size_t)LP;
     u32x4 *soff = st_off[wave];
     f32x4 *sfrac = st_frac[wave];
     f32x4 *smisc = st_misc[wave];
 
-    for (int pt = sub; pt < LP; pt += 8) {
+    // ---- set-up: lane (pair, c) prepares point c (and c + 32 for L > 8 ... LP <= 32) of its query ---------------
+    if (c < LP) {
+        const int pt = c;
         const f32x2 xy = *reinterpret_cast<const f32x2 *>(loc + (hrow + pt) * 2);
         const float a = attn[hrow + pt];
         const int l = pt / kBP;
         const int h = lvl.h[l], w = lvl.w[l];
         const float x = xy.x * (float)w - 0.5f, y = xy.y * (float)h - 0.5f;
-        const bool inside = (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);
+        const bool inside = qok && (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);
         const float xf = floorf(x), yf = floorf(y);
         const int x0 = inside ? (int)xf : 0, y0 = inside ? (int)yf : 0;
         const float lx = inside ? x - xf : 0.f, ly = inside ? y - yf : 0.f;   // NaN-safe
@@ -105,42 +104,48 @@ __global__ __launch_bounds__(kBWaves *kWave) void msda_bwd_wave_kernel(
         o.y = (okx1 && oky0) ? base + kBPixelBytes : kBInvalid;
         o.z = (okx0 && oky1) ? base + rowb : kBInvalid;
         o.w = (okx1 && oky1) ? base + rowb + kBPixelBytes : kBInvalid;
-        soff[pt * kBH + m] = o;
-        sfrac[pt * kBH + m] = f32x4{1.f - ly, 1.f - lx, ly, lx};
-        smisc[pt * kBH + m] = f32x4{inside ? a : 0.f, (float)w, (float)h, inside ? 1.f : 0.f};
+        soff[pt * 2 + pair] = o;
+        sfrac[pt * 2 + pair] = f32x4{1.f - ly, 1.f - lx, ly, lx};
+        smisc[pt * 2 + pair] = f32x4{inside ? a : 0.f, (float)w, (float)h, inside ? 1.f : 0.f};
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const f32x4 g = reinterpret_cast<const f32x4 *>(grad_out + row * (kBH * kBD))[lane];
+    const float g = grad_out[row * (kBH * kBD) + m * kBD + c];
+    float my_ga = 0.f, my_gx = 0.f, my_gy = 0.f;                  // results of point `c`, kept by lane c of the pair
 
 #pragma unroll 2
     for (int pt = 0; pt < LP; ++pt) {
-        const u32x4 o = soff[pt * kBH + m];
-        const f32x4 fr = sfrac[pt * kBH + m];       // hy, hx, ly, lx
-        const f32x4 mi = smisc[pt * kBH + m];       // attn (0 if outside), W, H, inside
-        const f32x4 v00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.x + lane_off, 0, 0));
-        const f32x4 v01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.y + lane_off, 0, 0));
-        const f32x4 v10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.z + lane_off, 0, 0));
-        const f32x4 v11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, o.w + lane_off, 0, 0));
+        const u32x4 o = soff[pt * 2 + pair];
+        const f32x4 fr = sfrac[pt * 2 + pair];      // hy, hx, ly, lx
+        const f32x4 mi = smisc[pt * 2 + pair];      // attn (0 if outside), W, H, inside
+        const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_v, o.x + lane_off, 0, 0));
+        const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_v, o.y + lane_off, 0, 0));
+        const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_v, o.z + lane_off, 0, 0));
+        const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_v, o.w + lane_off, 0, 0));
         const float hy = fr.x, hx = fr.y, ly = fr.z, lx = fr.w;
-        const f32x4 ga = g * mi.x;                                   // top_grad * attn_weight
-        atomic_add4(rs_g, o.x + lane_off, (hy * hx) * ga);
-        atomic_add4(rs_g, o.y + lane_off, (hy * lx) * ga);
-        atomic_add4(rs_g, o.z + lane_off, (ly * hx) * ga);
-        atomic_add4(rs_g, o.w + lane_off, (ly * lx) * ga);
+        const float ga = g * mi.x;                                   // top_grad * attn_weight
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((hy * hx) * ga, rs_g, o.x + lane_off, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((hy * lx) * ga, rs_g, o.y + lane_off, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((ly * hx) * ga, rs_g, o.z + lane_off, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((ly * lx) * ga, rs_g, o.w + lane_off, 0, 0);
         // d/dx and d/dy of the bilinear sample (ms_deform_im2col_cuda.cuh:102-141)
-        const f32x4 dxs = hy * (v01 - v00) + ly * (v11 - v10);
-        const f32x4 dys = hx * (v10 - v00) + lx * (v11 - v01);
-        const f32x4 smp = (hy * hx) * v00 + (hy * lx) * v01 + (ly * hx) * v10 + (ly * lx) * v11;
-        const float ga_w = sum8(dot4(g, smp)) * mi.w;                // grad wrt attention weight
-        const float gx = sum8(dot4(ga, dxs)) * mi.y;                 // * W_l
-        const float gy = sum8(dot4(ga, dys)) * mi.z;                 // * H_l
-        if (sub == (pt & 7)) {
-            grad_attn[hrow + pt] = ga_w;
-            *reinterpret_cast<f32x2 *>(grad_loc + (hrow + pt) * 2) = f32x2{gx, gy};
+        const float dxs = hy * (v01 - v00) + ly * (v11 - v10);
+        const float dys = hx * (v10 - v00) + lx * (v11 - v01);
+        const float smp = (hy * hx) * v00 + (hy * lx) * v01 + (ly * hx) * v10 + (ly * lx) * v11;
+        const float ga_w = sum32(g * smp) * mi.w;                    // grad wrt attention weight
+        const float gx = sum32(ga * dxs) * mi.y;                     // * W_l
+        const float gy = sum32(ga * dys) * mi.z;                     // * H_l
+        if (c == pt) {
+            my_ga = ga_w;
+            my_gx = gx;
+            my_gy = gy;
         }
+    }
+    if (qok && c < LP) {                                              // 16-20 contiguous floats per query-head
+        grad_attn[hrow + c] = my_ga;
+        *reinterpret_cast<f32x2 *>(grad_loc + (hrow + c) * 2) = f32x2{my_gx, my_gy};
     }
 }
 
@@ -215,8 +220,8 @@ extern "C" int rdetr_msda_backward_f32(const float *value, const int64_t *spatia
                       reinterpret_cast<uintptr_t>(grad_sampling_loc) % 8 == 0 &&
                       (long long)S * kBPixelBytes < (1ll << 31);
     if (fast) {
-        const int tiles = (Nq + kBWaves - 1) / kBWaves;
-        const long long nblk = (long long)B * tiles;
+        const int tiles = (Nq + 2 * kBWaves - 1) / (2 * kBWaves);
+        const long long nblk = (long long)B * kBH * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(msda_bwd_wave_kernel, dim3((unsigned)nblk), dim3(kBWaves * kWave), 0, st, value,
                            spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, S, L, Nq, tiles,

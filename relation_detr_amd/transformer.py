@@ -225,7 +225,9 @@ class RelationTransformer(nn.Module):
     @staticmethod
     def flatten_levels(levels: Sequence[Tensor]) -> Tensor:
         flat = torch.cat([t.flatten(-2) for t in levels], dim=-1)                   # [B,(C,)S]
-        return flat.transpose(1, 2) if flat.dim() == 3 else flat
+        # the reference leaves [B,S,C] as a transposed view (base_transformer.py:17-23); every later `x + pos` on that
+        # view is a strided kernel, so pay for one contiguous copy here instead
+        return flat.transpose(1, 2).contiguous() if flat.dim() == 3 else flat
 
     @staticmethod
     def level_misc(masks: Sequence[Tensor]):

@@ -112,6 +112,29 @@ int rdetr_msda_forward_fused_planned_bf16(const uint16_t *value, const int64_t *
                                           const float *reference_points, int ref_dim, int B, int S, int L, int Nq,
                                           uint16_t *out, void *stream);
 
+/* Explicit-strategy forms of the bf16 operator (H = 8, D = 32, P = 4 implied), for A/B measurement and tests; the
+ * plain entry points above choose between the two themselves (RDETR_MSDA_ALGO=q forces "direct"):
+ *   *_tiled_*   csrc/msda_tile.hip -- LDS-tiled kernel for the ENCODER shape: queries are the pyramid's own pixels in
+ *               level_start order (Nq == S), L == 4, S >= 4096.  Per 16x16 query tile and level, the window of the
+ *               value plane the tile samples (bounding box of its actual sample corners, clipped to the LDS buffer)
+ *               is copied L2 -> LDS by LDS-DMA and gathered from there; samples outside the window are fetched from
+ *               global memory, so results never depend on the window.  RDETR_ERR_UNSUPPORTED for any other shape.
+ *   *_direct_*  csrc/msda_fwd.hip -- the query-run kernel (range-checked global gathers), any Nq, L <= 8. */
+int rdetr_msda_forward_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                  const float *sampling_loc, const float *attn_weight, int B, int S, int L, int Nq,
+                                  uint16_t *out, void *stream);
+int rdetr_msda_forward_fused_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                        const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                        const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B,
+                                        int S, int L, int Nq, uint16_t *out, void *stream);
+int rdetr_msda_forward_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                   const float *sampling_loc, const float *attn_weight, int B, int S, int L, int Nq,
+                                   uint16_t *out, void *stream);
+int rdetr_msda_forward_fused_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                         const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B,
+                                         int S, int L, int Nq, uint16_t *out, void *stream);
+
 /* 1 if (H, D, L, P) is served by the query-run kernel, 0 if by the generic kernel. */
 int rdetr_msda_fast_path(int H, int D, int L, int P);
 

@@ -27,6 +27,10 @@ SIGNATURES = {
     "rdetr_msda_forward_planned_bf16": [_vp] * 6 + [_c_int] * 4 + [_vp, _vp],
     "rdetr_msda_forward_fused_planned_f32": [_vp] * 7 + [_c_int] * 5 + [_vp, _vp],
     "rdetr_msda_forward_fused_planned_bf16": [_vp] * 7 + [_c_int] * 5 + [_vp, _vp],
+    "rdetr_msda_forward_tiled_bf16": [_vp] * 5 + [_c_int] * 4 + [_vp, _vp],
+    "rdetr_msda_forward_direct_bf16": [_vp] * 5 + [_c_int] * 4 + [_vp, _vp],
+    "rdetr_msda_forward_fused_tiled_bf16": [_vp] * 6 + [_c_int] * 5 + [_vp, _vp],
+    "rdetr_msda_forward_fused_direct_bf16": [_vp] * 6 + [_c_int] * 5 + [_vp, _vp],
     "rdetr_msda_backward_f32": [_vp] * 6 + [_c_int] * 7 + [_vp] * 4,
     "rdetr_relation_bias_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp],
     "rdetr_bias_softmax_f32": [_vp] * 3 + [_c_int] * 3 + [_vp],

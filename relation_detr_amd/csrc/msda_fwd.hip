@@ -278,12 +278,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
         IO::load_run(rsrc, o.y + lane_off, v01);
         IO::load_run(rsrc, o.z + lane_off, v10);
         IO::load_run(rsrc, o.w + lane_off, v11);
+        // explicit FMAs (the file is built with -ffp-contract=off): the loop is VALU-bound at 1 wave-instruction/clk/CU
+        // (tools/microbench/valu_rate.hip), and mul + add costs twice the issue slots of v_pk_fma_f32
 #pragma unroll
         for (int c = 0; c < kCh; ++c) {
-            acc[c] += wt.x * v00[c];
-            acc[c] += wt.y * v01[c];
-            acc[c] += wt.z * v10[c];
-            acc[c] += wt.w * v11[c];
+            acc[c] = __builtin_fmaf(wt.x, v00[c], acc[c]);
+            acc[c] = __builtin_fmaf(wt.y, v01[c], acc[c]);
+            acc[c] = __builtin_fmaf(wt.z, v10[c], acc[c]);
+            acc[c] = __builtin_fmaf(wt.w, v11[c], acc[c]);
         }
     }
     if (qok) IO::store_run(out + row * (kHeads * kHeadDim) + m * kHeadDim + sub * kCh, acc);
@@ -344,6 +346,24 @@ static bool fast_path(int H, int D, int L, int P)
     return H == kHeads && D == kHeadDim && P == kPoints && L >= 1 && L <= kMaxLevels;
 }
 
+// csrc/msda_tile.hip: LDS-tiled kernel for the encoder shape (bf16, L == 4, Nq == S).
+template <bool FUSED>
+int msda_tile_forward(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
+                      const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, uint16_t *out,
+                      hipStream_t stream);
+
+// RDETR_MSDA_ALGO (read once): q(run, default) = the direct query-run kernel;  l(ds) = the LDS-tiled kernel
+// (csrc/msda_tile.hip) where it applies (bf16, L == 4, Nq == S);  h / t / s = the experimental strategies behind the
+// planned entry points.
+static char msda_algo()
+{
+    static const char algo = []() {
+        const char *e = getenv("RDETR_MSDA_ALGO");
+        return e ? e[0] : 'q';
+    }();
+    return algo;
+}
+
 template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
@@ -365,7 +385,7 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
 template <typename T, bool FUSED>
 static int msda_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
                         const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
-                        int P, T *out, hipStream_t stream, const int64_t *host_shapes = nullptr)
+                        int P, T *out, hipStream_t stream, const int64_t *host_shapes = nullptr, bool force_direct = false)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
     if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
@@ -377,6 +397,13 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *le
     const bool aligned = (reinterpret_cast<uintptr_t>(value) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
+        if constexpr (sizeof(T) == 2) {
+            if (msda_algo() == 'l' && !host_shapes && !force_direct) {
+                const int st = msda_tile_forward<FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, L, Nq,
+                                                        out, stream);
+                if (st != RDETR_ERR_UNSUPPORTED) return st;
+            }
+        }
         const int slots = kWave / ValueIO<T>::kRunSub;                       // queries per wave (8 fp32 / 16 bf16)
         const int qpb = kWavesPerBlock * slots;
         long long tiles = (Nq + qpb - 1) / qpb;
@@ -472,10 +499,7 @@ static int msda_planned(const T *value, const int64_t *shapes, const int64_t *le
 {
     if (!host_shapes) return RDETR_ERR_INVALID_ARG;
     if (B < 0 || S < 0 || Nq < 0 || L <= 0) return RDETR_ERR_INVALID_ARG;
-    static const char algo = []() {
-        const char *e = getenv("RDETR_MSDA_ALGO");
-        return e ? e[0] : 'q';
-    }();
+    const char algo = msda_algo();
     if (B > 0 && Nq > 0 && S > 0 && value && src_a && src_b && out && (!FUSED || ref)) {
         if (algo == 's' && Nq == S) {
             const int st = msda_sweep_forward<T, FUSED>(value, host_shapes, src_a, src_b, ref, ref_dim, B, S, L, out, stream);
@@ -531,4 +555,60 @@ extern "C" int rdetr_msda_forward_fused_planned_bf16(const uint16_t *value, cons
     return rdetr::msda_planned<uint16_t, true>(value, spatial_shapes, level_start_index, host_spatial_shapes,
                                                sampling_offsets, attn_logits, reference_points, ref_dim, B, S, L, Nq, out,
                                                static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Explicit-strategy entry points (A/B measurement, tests).
+namespace rdetr {
+template <bool FUSED>
+static int msda_tiled_entry(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
+                            const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, uint16_t *out,
+                            hipStream_t stream)
+{
+    if (B < 0 || S < 0 || Nq < 0 || L <= 0) return RDETR_ERR_INVALID_ARG;
+    if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
+    if (B == 0 || Nq == 0) return RDETR_OK;
+    if (!value || !shapes || !level_start || !src_a || !src_b || !out || (FUSED && !ref)) return RDETR_ERR_INVALID_ARG;
+    auto al = [](const void *p, unsigned a) { return reinterpret_cast<uintptr_t>(p) % a == 0; };
+    if (!al(value, 16) || !al(out, 16) || !al(src_a, 8) || !al(src_b, 4)) return RDETR_ERR_UNSUPPORTED;
+    return msda_tile_forward<FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, L, Nq, out, stream);
+}
+}  // namespace rdetr
+
+extern "C" int rdetr_msda_forward_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                             const int64_t *level_start_index, const float *sampling_loc,
+                                             const float *attn_weight, int B, int S, int L, int Nq, uint16_t *out,
+                                             void *stream)
+{
+    return rdetr::msda_tiled_entry<false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, 0,
+                                          B, S, L, Nq, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_forward_fused_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                                   const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                                   const uint16_t *attn_logits, const float *reference_points,
+                                                   int ref_dim, int B, int S, int L, int Nq, uint16_t *out, void *stream)
+{
+    return rdetr::msda_tiled_entry<true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                         reference_points, ref_dim, B, S, L, Nq, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_forward_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                              const int64_t *level_start_index, const float *sampling_loc,
+                                              const float *attn_weight, int B, int S, int L, int Nq, uint16_t *out,
+                                              void *stream)
+{
+    return rdetr::msda_forward<uint16_t, false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                                nullptr, 0, B, S, rdetr::kHeads, rdetr::kHeadDim, L, Nq, rdetr::kPoints,
+                                                out, static_cast<hipStream_t>(stream), nullptr, true);
+}
+
+extern "C" int rdetr_msda_forward_fused_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                                    const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                                    const uint16_t *attn_logits, const float *reference_points,
+                                                    int ref_dim, int B, int S, int L, int Nq, uint16_t *out, void *stream)
+{
+    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                               reference_points, ref_dim, B, S, rdetr::kHeads, rdetr::kHeadDim, L, Nq,
+                                               rdetr::kPoints, out, static_cast<hipStream_t>(stream), nullptr, true);
 }

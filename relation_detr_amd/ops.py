@@ -179,6 +179,44 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
     return out
 
 
+def ms_deform_attn_forward_strategy(strategy: str, value: torch.Tensor, spatial_shapes: torch.Tensor,
+                                    level_start_index: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
+                                    reference_points: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 MSDA through ONE named kernel (A/B measurement, tests): strategy "tiled" (csrc/msda_tile.hip, encoder
+    shape only -- raises RdetrError "unsupported" otherwise) or "direct" (csrc/msda_fwd.hip).  With
+    ``reference_points`` None, (a, b) = (sampling_loc, attn_weight) fp32 as in ms_deform_attn_forward; else
+    (a, b) = raw (sampling_offsets, attn_logits) bf16 as in ms_deform_attn_forward_fused."""
+    if strategy not in ("tiled", "direct"):
+        raise ValueError("strategy must be 'tiled' or 'direct'")
+    fused = reference_points is not None
+    _require_device(value, spatial_shapes, level_start_index, a, b, reference_points)
+    _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index, a=a, b=b,
+                        reference_points=reference_points)
+    B, S, H, D = value.shape
+    _, Nq, H2, L, P, two = a.shape
+    if value.dtype != torch.bfloat16 or (H, D, P, H2, two) != (8, 32, 4, 8, 2) or a.shape[0] != B:
+        raise _lib.RdetrError("strategy entry points serve bf16 value with H = 8, D = 32, P = 4")
+    want = torch.bfloat16 if fused else torch.float32
+    if a.dtype != want or b.dtype != want or b.numel() != B * Nq * H * L * P:
+        raise _lib.RdetrError("sampling tensors have the wrong dtype or shape")
+    if fused and (reference_points.dtype != torch.float32 or tuple(reference_points.shape[:3]) != (B, Nq, L)
+                  or reference_points.shape[-1] not in (2, 4)):
+        raise _lib.RdetrError("reference_points must be float32 [B, Nq, L, 2|4]")
+    check_levels(spatial_shapes, level_start_index, S)
+    lib = _lib.load()
+    out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if fused:
+        fn = getattr(lib, f"rdetr_msda_forward_fused_{strategy}_bf16")
+        st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
+                reference_points.data_ptr(), reference_points.shape[-1], B, S, L, Nq, out.data_ptr(), _stream_ptr(value))
+    else:
+        fn = getattr(lib, f"rdetr_msda_forward_{strategy}_bf16")
+        st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
+                B, S, L, Nq, out.data_ptr(), _stream_ptr(value))
+    _lib.check(st, f"rdetr_msda_forward_{strategy}")
+    return out
+
+
 def msda_fast_path(H: int, D: int, L: int, P: int) -> bool:
     return bool(_lib.load().rdetr_msda_fast_path(H, D, L, P))
 

@@ -178,6 +178,19 @@ int rdetr_relation_bias_f32(const float *src, const float *tgt, const float *pro
 int rdetr_bias_softmax_f32(float *scores, const float *bias, const uint8_t *mask, int BH, int N1, int N2,
                            void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Residual add + LayerNorm over the last dimension, one pass (callers either side of the hot path).
+ * Replaces the pairs  x + sublayer(x) -> nn.LayerNorm  of the encoder / decoder layers
+ *           models/bricks/relation_transformer.py:262-276 (encoder layer), :452-478 (decoder layer), :360.
+ *   x, residual (nullable), out  [rows, C]      gamma, beta [C]      all in one dtype (fp32 / bf16)
+ *   out = (x + residual - mean) / sqrt(var + eps) * gamma + beta, statistics in fp32, biased variance
+ *   (torch.nn.functional.layer_norm); the sum is not rounded to the storage type before normalising.
+ * C = 256 with 16-byte-aligned pointers takes the vectorised kernel; any other C <= 8192 a strided one. */
+int rdetr_add_layernorm_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                            long long rows, int C, float eps, float *out, void *stream);
+int rdetr_add_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma, const uint16_t *beta,
+                             long long rows, int C, float eps, uint16_t *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

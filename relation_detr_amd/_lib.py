@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librelation_detr_amd.so")
 
-_c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_c_int, _c_float, _vp, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 
 # name -> argtypes (restype is int unless noted); mirrors include/relation_detr_amd.h one to one.
 SIGNATURES = {
@@ -34,6 +34,8 @@ SIGNATURES = {
     "rdetr_msda_backward_f32": [_vp] * 6 + [_c_int] * 7 + [_vp] * 4,
     "rdetr_relation_bias_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp],
     "rdetr_bias_softmax_f32": [_vp] * 3 + [_c_int] * 3 + [_vp],
+    "rdetr_add_layernorm_f32": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
+    "rdetr_add_layernorm_bf16": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
 }
 
 _lib = None

@@ -1,0 +1,146 @@
+// Residual add + LayerNorm in one pass, for the rows either side of the hot-path kernels (gfx950).
+//
+// Replaces the pairs  `x + sublayer(x)` -> nn.LayerNorm  of the reference's encoder / decoder layers
+// (models/bricks/relation_transformer.py:262-276 encoder layer, :452-478 decoder layer, :360 decoder norm):
+// two elementwise passes + a normalisation pass (5 tensor traversals) become one read of each operand and one write.
+//
+//   one 64-lane wavefront per row; C = 256 (the model's embed_dim): a lane owns 4 consecutive channels (8-byte bf16 /
+//   16-byte fp32 accesses, one coalesced row per wave instruction); any other C <= 8192: strided scalar loop.
+//   Statistics in fp32, two-pass in registers (mean, then the variance of the centred values), biased variance and
+//   1/sqrt(var + eps) as torch.nn.functional.layer_norm; the sum x + r is NOT rounded to the storage type first.
+// Bound: HBM (3 x rows x C x sizeof(T) bytes per call).
+#include "common.h"
+
+namespace rdetr {
+
+template <typename T> struct LnIO;
+template <> struct LnIO<float> {
+    static __device__ __forceinline__ void load4(const float *p, float (&v)[4])
+    {
+        const f32x4 r = *reinterpret_cast<const f32x4 *>(p);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+    static __device__ __forceinline__ void store4(float *p, const float (&v)[4])
+    {
+        *reinterpret_cast<f32x4 *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
+};
+template <> struct LnIO<uint16_t> {
+    static __device__ __forceinline__ void load4(const uint16_t *p, float (&v)[4])
+    {
+        const u32x2 r = *reinterpret_cast<const u32x2 *>(p);
+        v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store4(uint16_t *p, const float (&v)[4])
+    {
+        u32x2 o;
+        o.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+        o.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<u32x2 *>(p) = o;
+    }
+    static __device__ __forceinline__ float load1(const uint16_t *p) { return bf16_bits_to_f32(*p); }
+    static __device__ __forceinline__ void store1(uint16_t *p, float v) { *p = (uint16_t)f32_to_bf16_bits(v); }
+};
+
+__device__ __forceinline__ float ln_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int kLnWaves = 4;
+
+template <typename T>
+__global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm256_kernel(const T *__restrict__ x, const T *__restrict__ r,
+                                                                           const T *__restrict__ gamma,
+                                                                           const T *__restrict__ beta, long long rows,
+                                                                           float eps, T *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * kLnWaves + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int c = (threadIdx.x & 63) * 4;
+    float v[4], g[4], b[4];
+    LnIO<T>::load4(x + row * 256 + c, v);
+    if (r) {
+        float t[4];
+        LnIO<T>::load4(r + row * 256 + c, t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
+    LnIO<T>::load4(gamma + c, g);
+    LnIO<T>::load4(beta + c, b);
+    const float mean = ln_wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+    float d[4], sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        d[i] = v[i] - mean;
+        sq += d[i] * d[i];
+    }
+    const float rstd = 1.0f / sqrtf(ln_wave_sum(sq) * (1.0f / 256.0f) + eps);
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = d[i] * rstd * g[i] + b[i];
+    LnIO<T>::store4(out + row * 256 + c, y);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm_generic_kernel(const T *__restrict__ x, const T *__restrict__ r,
+                                                                                const T *__restrict__ gamma,
+                                                                                const T *__restrict__ beta, long long rows,
+                                                                                int C, float eps, T *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * kLnWaves + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const T *xr = x + row * C, *rr = r ? r + row * C : nullptr;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += LnIO<T>::load1(xr + c) + (rr ? LnIO<T>::load1(rr + c) : 0.f);
+    const float mean = ln_wave_sum(s) / (float)C;
+    float sq = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = LnIO<T>::load1(xr + c) + (rr ? LnIO<T>::load1(rr + c) : 0.f) - mean;
+        sq += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(ln_wave_sum(sq) / (float)C + eps);
+    for (int c = lane; c < C; c += 64) {
+        const float d = LnIO<T>::load1(xr + c) + (rr ? LnIO<T>::load1(rr + c) : 0.f) - mean;
+        LnIO<T>::store1(out + row * C + c, d * rstd * LnIO<T>::load1(gamma + c) + LnIO<T>::load1(beta + c));
+    }
+}
+
+template <typename T>
+static int add_layernorm(const T *x, const T *r, const T *gamma, const T *beta, long long rows, int C, float eps, T *out,
+                         hipStream_t stream)
+{
+    if (rows < 0 || C <= 0 || C > 8192) return RDETR_ERR_INVALID_ARG;
+    if (rows == 0) return RDETR_OK;
+    if (!x || !gamma || !beta || !out) return RDETR_ERR_INVALID_ARG;
+    const long long nblk = (rows + kLnWaves - 1) / kLnWaves;
+    if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
+    auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (C == 256 && al16(x) && al16(out) && al16(gamma) && al16(beta) && (!r || al16(r)))
+        hipLaunchKernelGGL((add_layernorm256_kernel<T>), dim3((unsigned)nblk), dim3(kLnWaves * kWave), 0, stream, x, r, gamma,
+                           beta, rows, eps, out);
+    else
+        hipLaunchKernelGGL((add_layernorm_generic_kernel<T>), dim3((unsigned)nblk), dim3(kLnWaves * kWave), 0, stream, x, r,
+                           gamma, beta, rows, C, eps, out);
+    return launch_status();
+}
+
+}  // namespace rdetr
+
+extern "C" int rdetr_add_layernorm_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                                       long long rows, int C, float eps, float *out, void *stream)
+{
+    return rdetr::add_layernorm<float>(x, residual, gamma, beta, rows, C, eps, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_add_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma,
+                                        const uint16_t *beta, long long rows, int C, float eps, uint16_t *out, void *stream)
+{
+    return rdetr::add_layernorm<uint16_t>(x, residual, gamma, beta, rows, C, eps, out, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,49 @@
+"""HIP-graph replay of the eval forward for fixed input shapes (serving path).
+
+The transformer stack launches a few hundred small kernels per image batch; enqueueing them from Python costs about as
+much wall time as the GPU needs to run them.  Every operator of this package only enqueues work on the current stream
+(include/relation_detr_amd.h: no allocation, no synchronisation, no global state), and the harness keeps all
+shape-dependent tables on the device (RelationTransformer.level_geometry), so the whole forward can be captured once
+into a hipGraph and replayed with one launch per batch.
+
+    run = GraphedCall(lambda f0, ..., m0, ..., p0, ...: net(...), example_tensors)
+    out = run(*tensors)        # tensors with the captured shapes / dtypes; copied into the static inputs if they are
+                               # not the captured objects themselves; the returned tensors are overwritten by the next call
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+
+from . import _lib
+
+
+class GraphedCall:
+    def __init__(self, fn: Callable, example_inputs: Sequence[torch.Tensor], warmup: int = 3):
+        if not example_inputs or not all(t.is_cuda for t in example_inputs):
+            raise _lib.RdetrError("GraphedCall needs device tensors (there is no CPU path)")
+        _lib.load()
+        self._fn = fn
+        self._inputs = list(example_inputs)             # the captured objects: replay reads these buffers
+        side = torch.cuda.Stream(device=self._inputs[0].device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():  # warm-up outside capture: host-side caches, lazy handles, autotuning
+            for _ in range(max(1, warmup)):
+                fn(*self._inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph), torch.no_grad():
+            self._outputs = fn(*self._inputs)
+
+    def __call__(self, *inputs: torch.Tensor):
+        if len(inputs) != len(self._inputs):
+            raise _lib.RdetrError(f"expected {len(self._inputs)} tensors, got {len(inputs)}")
+        for dst, src in zip(self._inputs, inputs):
+            if src is not dst:
+                if src.shape != dst.shape or src.dtype != dst.dtype:
+                    raise _lib.RdetrError("GraphedCall: input shape / dtype differs from the captured one")
+                dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._outputs

@@ -80,7 +80,10 @@ class MultiScaleDeformableAttention(nn.Module):
         H, L, P = self.num_heads, self.num_levels, self.num_points
         v = self.value_proj(value)
         if key_padding_mask is not None:
-            v = v.masked_fill(key_padding_mask[..., None], float(0))
+            if torch.is_grad_enabled() and v.requires_grad:
+                v = v.masked_fill(key_padding_mask[..., None], float(0))
+            else:                                      # inference: fill the fresh projection in place (no clone pass)
+                v.masked_fill_(key_padding_mask[..., None], float(0))
         v = v.view(B, S, H, self.embed_dim // H)
         offsets = self.sampling_offsets(query).view(B, Nq, H, L, P, 2)
         logits = self.attention_weights(query).view(B, Nq, H, L * P)

@@ -315,3 +315,26 @@ def bias_softmax_(scores: torch.Tensor, bias: Optional[torch.Tensor] = None,
                                             _stream_ptr(scores))
     _lib.check(st, "rdetr_bias_softmax_f32")
     return scores
+
+
+def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
+                   eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm(x + residual) over the last dimension in one pass (fp32 / bf16; residual may be None).
+    Inference-only (no autograd): the harness uses it under torch.no_grad()."""
+    _require_device(x, residual, weight, bias)
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.RdetrError(f"add_layer_norm: dtype {x.dtype} not supported (float32 or bfloat16)")
+    C = x.shape[-1]
+    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype):
+        raise _lib.RdetrError("add_layer_norm: residual must have x's shape and dtype")
+    if weight.numel() != C or bias.numel() != C:
+        raise _lib.RdetrError("add_layer_norm: weight / bias must have C elements")
+    x = x.contiguous()
+    residual = None if residual is None else residual.contiguous()
+    w, b = weight.detach().to(x.dtype).contiguous(), bias.detach().to(x.dtype).contiguous()
+    out = torch.empty_like(x)
+    fn = _lib.load().rdetr_add_layernorm_f32 if x.dtype == torch.float32 else _lib.load().rdetr_add_layernorm_bf16
+    st = fn(x.data_ptr(), None if residual is None else residual.data_ptr(), w.data_ptr(), b.data_ptr(),
+            x.numel() // C, C, float(eps), out.data_ptr(), _stream_ptr(x))
+    _lib.check(st, "rdetr_add_layernorm")
+    return out

@@ -42,8 +42,29 @@ def sine_pos_embed(pos: Tensor, num_pos_feats: int = 128, temperature: float = 1
     dim_t = temperature ** (k * 2 / num_pos_feats)
     ang = pos.unsqueeze(-1) * scale / dim_t
     emb = torch.stack((ang.sin(), ang.cos()), dim=-1).flatten(-2)            # [..., n, F]
-    order = [1, 0] + list(range(2, pos.shape[-1]))
-    return emb[..., order, :].flatten(-2)
+    # swap the first two coordinates with slices (an index list would be uploaded from the host on every call,
+    # which a HIP-graph capture does not allow)
+    return torch.cat((emb[..., 1:2, :], emb[..., 0:1, :], emb[..., 2:, :]), dim=-2).flatten(-2)
+
+
+def add_norm(norm: nn.LayerNorm, x: Tensor, residual: Tensor = None) -> Tensor:
+    """norm(x + residual).  On a ROCm device without autograd: one HIP kernel (rdetr_add_layernorm_*, csrc/layernorm.hip)
+    instead of an add pass and a normalisation pass; otherwise (CPU oracle harness, training) plain torch."""
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or norm.weight.requires_grad or
+                                              (residual is not None and residual.requires_grad))
+    if x.is_cuda and not needs_grad and x.dtype in (torch.float32, torch.bfloat16):
+        from . import ops
+        return ops.add_layer_norm(x, residual, norm.weight, norm.bias, norm.eps)
+    return norm(x if residual is None else x + residual)
+
+
+def linear_relu(linear: nn.Linear, x: Tensor) -> Tensor:
+    """relu(linear(x)); on a device the ReLU runs in the GEMM's epilogue (hipBLASLt) instead of a pass of its own over
+    the [.., d_ffn] activations."""
+    if x.is_cuda and linear.bias is not None and not (torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)):
+        y = torch._addmm_activation(linear.bias, x.reshape(-1, x.shape[-1]), linear.weight.t(), use_gelu=False)
+        return y.view(*x.shape[:-1], linear.out_features)
+    return F.relu(linear(x))
 
 
 class MLP(nn.Module):
@@ -60,9 +81,7 @@ class MLP(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i + 1 < self.num_layers:
-                x = F.relu(x)
+            x = linear_relu(layer, x) if i + 1 < self.num_layers else layer(x)
         return x
 
 
@@ -82,8 +101,8 @@ class RelationTransformerEncoderLayer(nn.Module):
         attn = self.self_attn(query=query if query_pos is None else query + query_pos, reference_points=reference_points,
                               value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               key_padding_mask=key_padding_mask)
-        query = self.norm1(query + attn)
-        return self.norm2(query + self.linear2(F.relu(self.linear1(query))))
+        query = add_norm(self.norm1, query, attn)
+        return add_norm(self.norm2, query, self.linear2(linear_relu(self.linear1, query)))
 
 
 class RelationTransformerEncoder(nn.Module):
@@ -103,7 +122,8 @@ class RelationTransformerEncoder(nn.Module):
         for layer in self.layers:
             query = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask)
             outs.append(query)
-        return self.memory_fusion(torch.cat(outs, -1))
+        fuse = self.memory_fusion
+        return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], torch.cat(outs, -1))))
 
 
 class RelationTransformerDecoderLayer(nn.Module):
@@ -124,13 +144,13 @@ class RelationTransformerDecoderLayer(nn.Module):
     def forward(self, query, query_pos, reference_points, value, spatial_shapes, level_start_index, self_attn_mask=None,
                 key_padding_mask=None):
         qp = query + query_pos
-        query = self.norm2(query + self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask,
-                                                  need_weights=False)[0])
+        query = add_norm(self.norm2, query, self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask,
+                                                           need_weights=False)[0])
         cross = self.cross_attn(query=query + query_pos, reference_points=reference_points, value=value,
                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                 key_padding_mask=key_padding_mask)
-        query = self.norm1(query + cross)
-        return self.norm3(query + self.linear2(F.relu(self.linear1(query))))
+        query = add_norm(self.norm1, query, cross)
+        return add_norm(self.norm3, query, self.linear2(linear_relu(self.linear1, query)))
 
 
 class RelationTransformerDecoder(nn.Module):
@@ -171,9 +191,10 @@ class RelationTransformerDecoder(nn.Module):
             query = layer(query=query, query_pos=query_pos, reference_points=ref_in, value=value,
                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                           key_padding_mask=key_padding_mask, self_attn_mask=pos_relation)
-            normed = self.norm(query)
+            normed = add_norm(self.norm, query)
             out_class = self.class_head[idx](normed)
-            out_coord = (self.bbox_head[idx](normed) + inverse_sigmoid(reference_points)).sigmoid()
+            # boxes stay fp32 whatever the network dtype (a bf16 + fp32 add takes torch's slow mixed-dtype kernel)
+            out_coord = (self.bbox_head[idx](normed).float() + inverse_sigmoid(reference_points)).sigmoid()
             classes.append(out_class)
             coords.append(out_coord)
             if idx == self.num_layers - 1:
@@ -184,7 +205,7 @@ class RelationTransformerDecoder(nn.Module):
                 pos_relation = self.position_relation_embedding(src_boxes, tgt_boxes).flatten(0, 1)
                 if attn_mask is not None:
                     pos_relation.masked_fill_(attn_mask, float("-inf"))
-            reference_points = (self.bbox_head[idx](query) + inverse_sigmoid(reference_points.detach())).sigmoid()
+            reference_points = (self.bbox_head[idx](query).float() + inverse_sigmoid(reference_points.detach())).sigmoid()
         return torch.stack(classes), torch.stack(coords)
 
 
@@ -229,31 +250,49 @@ class RelationTransformer(nn.Module):
         # view is a strided kernel, so pay for one contiguous copy here instead
         return flat.transpose(1, 2).contiguous() if flat.dim() == 3 else flat
 
-    @staticmethod
-    def level_misc(masks: Sequence[Tensor]):
-        shapes = masks[0].new_tensor([m.shape[-2:] for m in masks], dtype=torch.int64)
-        start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    # Everything that depends only on the pyramid's level shapes is built once per (shapes, device) and kept: the shape
+    # tables, each pixel's centre / level size / level index and the proposal sizes.  Nothing in `forward` then reads a
+    # device tensor back or uploads a host one, so the whole eval forward can be captured in a HIP graph (graph.py).
+    _geometry_cache: dict = {}
+
+    @classmethod
+    def level_geometry(cls, level_hw: Sequence[tuple], device) -> dict:
+        key = (tuple(level_hw), str(device))
+        geo = cls._geometry_cache.get(key)
+        if geo is None:
+            shapes = torch.tensor(level_hw, dtype=torch.int64, device=device)
+            start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+            centre, size, index, prop = [], [], [], []
+            for lvl, (h, w) in enumerate(level_hw):
+                ys, xs = torch.meshgrid(torch.arange(0.5, h + 0.5, device=device), torch.arange(0.5, w + 0.5, device=device),
+                                        indexing="ij")
+                centre.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
+                size.append(torch.tensor([w, h], dtype=torch.float32, device=device).expand(h * w, 2))
+                index.append(torch.full((h * w,), lvl, dtype=torch.int64, device=device))
+                prop.append(torch.full((h * w, 2), 0.05 * 2.0 ** lvl, dtype=torch.float32, device=device))
+            geo = dict(shapes=shapes, start=start, centre=torch.cat(centre), size=torch.cat(size), index=torch.cat(index),
+                       proposal_wh=torch.cat(prop))
+            if len(cls._geometry_cache) > 16:
+                cls._geometry_cache.clear()
+            cls._geometry_cache[key] = geo
+        return geo
+
+    @classmethod
+    def level_misc(cls, masks: Sequence[Tensor]):
+        geo = cls.level_geometry([tuple(m.shape[-2:]) for m in masks], masks[0].device)
         ratios = []
         for m in masks:
             _, h, w = m.shape
             ratios.append(torch.stack([(~m[:, 0, :]).sum(1).float() / w, (~m[:, :, 0]).sum(1).float() / h], -1))
-        return shapes, start, torch.stack(ratios, 1)                                # valid_ratios [B,L,2] (w,h)
+        return geo, torch.stack(ratios, 1)                                          # valid_ratios [B,L,2] (w,h)
 
     @staticmethod
-    def reference_and_proposals(spatial_shapes: Tensor, valid_ratios: Tensor):
-        full = []
-        for lvl, (h, w) in enumerate(spatial_shapes.tolist()):
-            ys, xs = torch.meshgrid(torch.arange(0.5, h + 0.5, device=valid_ratios.device),
-                                    torch.arange(0.5, w + 0.5, device=valid_ratios.device), indexing="ij")
-            ry = ys.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * h)
-            rx = xs.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * w)
-            full.append(torch.stack((rx, ry), -1))
-        full = torch.cat(full, 1)                                                   # [B,S,2]
+    def reference_and_proposals(geo: dict, valid_ratios: Tensor):
+        # pixel centre / (valid_ratio of its level * level size): the same quotient as base_transformer.py:57-70
+        full = geo["centre"][None] / (valid_ratios[:, geo["index"]] * geo["size"][None])      # [B,S,2]
         reference = full[:, :, None] * valid_ratios[:, None]                        # [B,S,L,2]
-        areas = spatial_shapes.prod(-1)
-        level_wh = 0.05 * 2.0 ** torch.arange(spatial_shapes.shape[0], device=full.device, dtype=full.dtype)
-        level_wh = level_wh.repeat_interleave(areas)[None, :, None].expand(full.shape[0], -1, 2)
-        return reference, torch.cat([full, level_wh], -1)
+        prop = geo["proposal_wh"][None].expand(full.shape[0], -1, -1)
+        return reference, torch.cat([full, prop], -1)
 
     def encoder_output(self, memory: Tensor, proposals: Tensor, padding_mask: Tensor):
         valid = ((proposals > 0.01) & (proposals < 0.99)).all(-1, keepdim=True)
@@ -267,8 +306,9 @@ class RelationTransformer(nn.Module):
         feat = self.flatten_levels(multi_level_feats)
         mask = self.flatten_levels(multi_level_masks)
         pos = self.flatten_levels([p + e.view(1, -1, 1, 1) for p, e in zip(multi_level_pos_embeds, self.level_embeds)])
-        shapes, start, valid_ratios = self.level_misc(multi_level_masks)
-        reference, proposals = self.reference_and_proposals(shapes, valid_ratios)
+        geo, valid_ratios = self.level_misc(multi_level_masks)
+        shapes, start = geo["shapes"], geo["start"]
+        reference, proposals = self.reference_and_proposals(geo, valid_ratios)
 
         memory = self.encoder(query=feat, query_pos=pos, query_key_padding_mask=mask, spatial_shapes=shapes,
                               level_start_index=start, reference_points=reference)

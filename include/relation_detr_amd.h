@@ -179,6 +179,22 @@ int rdetr_bias_softmax_f32(float *scores, const float *bias, const uint8_t *mask
                            void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Decoder self-attention with the relation bias, fused:
+ *   out = softmax(Q K^T * scale + bias [, bool mask]) V     per (image, head), bf16 activations, fp32 soft-max.
+ * Replaces the attention core of the nn.MultiheadAttention call of the decoder layer
+ *           models/bricks/relation_transformer.py:452-461 with the float bias of :369-374 as attn_mask
+ * (QK^T GEMM, bias add, softmax, PV GEMM and the dtype copies between them) by one flash-style MFMA kernel.
+ *   q [B, N, ..], k / v [B, M, ..]   bf16, head h at columns h*D .. h*D+D-1 of a row; ldq / ldk / ldv = row stride in
+ *                                    ELEMENTS (so slices of a packed in-projection output can be passed as they are),
+ *                                    image stride = rows * ld
+ *   bias  fp32 [B*H, N, M] or NULL (may hold -inf);   bool_mask u8 [N, M] or NULL (non-zero = excluded)
+ *   out   bf16 [B, N, ..] with row stride ldo;  D = 32 only (RDETR_ERR_UNSUPPORTED otherwise)
+ * A fully masked row yields NaN, as torch.softmax does. */
+int rdetr_relation_attention_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, int ldq, int ldk, int ldv,
+                                  const float *bias, const uint8_t *bool_mask, int B, int H, int D, int N, int M,
+                                  float scale, uint16_t *out, int ldo, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Residual add + LayerNorm over the last dimension, one pass (callers either side of the hot path).
  * Replaces the pairs  x + sublayer(x) -> nn.LayerNorm  of the encoder / decoder layers
  *           models/bricks/relation_transformer.py:262-276 (encoder layer), :452-478 (decoder layer), :360.

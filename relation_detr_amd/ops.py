@@ -338,3 +338,41 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
             x.numel() // C, C, float(eps), out.data_ptr(), _stream_ptr(x))
     _lib.check(st, "rdetr_add_layernorm")
     return out
+
+
+def relation_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, bias: Optional[torch.Tensor] = None,
+                       mask: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(Q K^T * scale + bias) V per (image, head) in one kernel (bf16, head dim 32, inference).
+    q [B,N,C], k / v [B,M,C] bf16 -- row-strided views are fine (last dim contiguous, image stride = rows * row stride);
+    bias fp32 [B*H,N,M] or None; mask bool [N,M] (True = excluded) or None -> [B,N,C] bf16."""
+    _require_device(q, k, v, bias, mask)
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise _lib.RdetrError("relation_attention: q, k, v must be bfloat16")
+    B, N, C = q.shape
+    M = k.shape[1]
+    if C % num_heads or k.shape != (B, M, C) or v.shape != (B, M, C):
+        raise _lib.RdetrError("relation_attention: q [B,N,C], k / v [B,M,C] expected")
+    D = C // num_heads
+
+    def rows(t, n):
+        if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != n * t.stride(1)):
+            t = t.contiguous()
+        return t, t.stride(1)
+
+    (q, ldq), (k, ldk), (v, ldv) = rows(q, N), rows(k, M), rows(v, M)
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != B * num_heads * N * M:
+            raise _lib.RdetrError("relation_attention: bias must be float32 [B*H, N, M]")
+        bias = bias.contiguous()
+    mask_u8 = None
+    if mask is not None:
+        if tuple(mask.shape) != (N, M):
+            raise _lib.RdetrError("relation_attention: mask must be [N, M]")
+        mask_u8 = mask.to(torch.uint8).contiguous()
+    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=q.device)
+    st = _lib.load().rdetr_relation_attention_bf16(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), ldq, ldk, ldv, None if bias is None else bias.data_ptr(),
+        None if mask_u8 is None else mask_u8.data_ptr(), B, num_heads, D, N, M,
+        float(scale if scale is not None else D ** -0.5), out.data_ptr(), C, _stream_ptr(q))
+    _lib.check(st, "rdetr_relation_attention_bf16")
+    return out

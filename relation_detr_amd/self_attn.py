@@ -72,6 +72,15 @@ class RelationSelfAttention(nn.Module):
             q = F.linear(query, self.in_proj_weight[:C], self.in_proj_bias[:C])
             k = F.linear(key, self.in_proj_weight[C:2 * C], self.in_proj_bias[C:2 * C])
         v = F.linear(value, self.in_proj_weight[2 * C:], self.in_proj_bias[2 * C:])
+        needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+        if (q.is_cuda and q.dtype == torch.bfloat16 and d == 32 and not needs_grad
+                and (attn_mask is None or attn_mask.dtype == torch.bool and attn_mask.dim() == 2
+                     or attn_mask.dtype != torch.bool and attn_mask.numel() == B * H * N * M)):
+            # inference, bf16: QK^T + bias + softmax + PV in one flash-style kernel (csrc/attn.hip)
+            is_bool = attn_mask is not None and attn_mask.dtype == torch.bool
+            ctx = ops.relation_attention(q, k, v, H, None if attn_mask is None or is_bool else attn_mask.float(),
+                                         attn_mask if is_bool else None, 1.0 / math.sqrt(d))
+            return self.out_proj(ctx), None
         q = q.view(B, N, H, d).transpose(1, 2)
         k = k.view(B, M, H, d).transpose(1, 2)
         v = v.view(B, M, H, d).transpose(1, 2)

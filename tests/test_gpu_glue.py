@@ -84,3 +84,83 @@ def test_graph_replay_matches_eager(dtype):
         replay = run(*inputs).clone()
         torch.cuda.synchronize()
         assert torch.equal(eager, replay)
+
+
+# ------------------------------------------------------------------------------------------ fused decoder self-attention
+def _attn_reference(q, k, v, H, bias, mask, scale):
+    """fp32 softmax(QK^T * scale + bias) V on the bf16-rounded inputs (the arithmetic of relation_transformer.py:452-461
+    with the float attn_mask of :369-374)."""
+    B, N, C = q.shape
+    M, d = k.shape[1], C // H
+    qh = q.float().view(B, N, H, d).transpose(1, 2)
+    kh = k.float().view(B, M, H, d).transpose(1, 2)
+    vh = v.float().view(B, M, H, d).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if bias is not None:
+        s = s + bias.view(B, H, N, M)
+    if mask is not None:
+        s = s.masked_fill(mask, float("-inf"))
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("B,N,M,with_bias,with_mask", [
+    (4, 900, 900, True, False),        # BASELINE.json configs[1]/[3]: 900 queries
+    (2, 300, 300, True, False),        # 300 queries
+    (1, 37, 37, False, False),         # layer 0: no bias, one partial tile
+    (2, 130, 97, True, True),          # N != M, key count not a multiple of 4 (scalar bias path), boolean mask
+    (1, 64, 1100, True, False),        # more keys than queries (denoising-sized)
+    (3, 1, 5, True, True),
+])
+def test_relation_attention_vs_reference(B, N, M, with_bias, with_mask):
+    from relation_detr_amd import ops
+    H, C = 8, 256
+    g = torch.Generator().manual_seed(N * 7 + M)
+    q = torch.randn(B, N, C, generator=g).to(torch.bfloat16).to(DEV)
+    k = torch.randn(B, M, C, generator=g).to(torch.bfloat16).to(DEV)
+    v = torch.randn(B, M, C, generator=g).to(torch.bfloat16).to(DEV)
+    bias = (torch.randn(B * H, N, M, generator=g).abs() * 2).to(DEV) if with_bias else None
+    mask = None
+    if with_mask:
+        mask = (torch.rand(N, M, generator=g) < 0.3)
+        mask[:, 0] = False                                   # keep every row alive
+        mask = mask.to(DEV)
+    out = ops.relation_attention(q, k, v, H, bias, mask, 32 ** -0.5).float()
+    ref = _attn_reference(q, k, v, H, bias, mask, 32 ** -0.5)
+    err = (out - ref).abs()
+    # P is rounded to bf16 before the PV product and the output once more: 2^-7 relative + a small absolute term
+    assert (err <= 2.0 ** -7 * ref.abs() + 4e-3).all(), (err.max().item(), ref.abs().max().item())
+
+
+def test_relation_attention_strided_views_inf_bias_and_masked_rows():
+    from relation_detr_amd import ops
+    H, C, B, N = 8, 256, 2, 70
+    g = torch.Generator().manual_seed(3)
+    qk = torch.randn(B, N, 2 * C, generator=g).to(torch.bfloat16).to(DEV)       # packed in-projection output
+    v = torch.randn(B, N, C, generator=g).to(torch.bfloat16).to(DEV)
+    q, k = qk[..., :C], qk[..., C:]
+    bias = torch.randn(B * H, N, N, generator=g).to(DEV)
+    bias[:, :, 5] = float("-inf")                        # a key nobody may attend to (denoising mask, :373-374)
+    bias[3, 11, :] = float("-inf")                       # one fully masked row -> NaN like torch.softmax
+    out = ops.relation_attention(q, k, v, H, bias, None).float()
+    ref = _attn_reference(q.contiguous(), k.contiguous(), v, H, bias, None, 32 ** -0.5)
+    dead = torch.isnan(ref)
+    assert dead.any() and torch.equal(torch.isnan(out), dead)
+    err = (out - ref).abs()[~dead]
+    assert (err <= 2.0 ** -7 * ref[~dead].abs() + 4e-3).all()
+
+
+def test_self_attention_module_fused_path_matches_unfused():
+    """RelationSelfAttention in bf16 eval takes the fused kernel; with autograd on it takes the GEMM + bias-softmax
+    path: the two agree to bf16 rounding."""
+    from relation_detr_amd.self_attn import RelationSelfAttention
+    torch.manual_seed(0)
+    mod = RelationSelfAttention(256, 8, batch_first=True).to(DEV).to(torch.bfloat16)
+    x = torch.randn(2, 300, 256, device=DEV).to(torch.bfloat16)
+    pos = torch.randn(2, 300, 256, device=DEV).to(torch.bfloat16)
+    bias = torch.randn(16, 300, 300, device=DEV).abs()
+    with torch.no_grad():
+        fused = mod(x + pos, x + pos, x, attn_mask=bias)[0].float()
+    xg = x.clone().requires_grad_(True)
+    unfused = mod(xg + pos, xg + pos, xg, attn_mask=bias)[0].float().detach()
+    assert (fused - unfused).abs().max().item() < 3e-2
+    assert (fused - unfused).abs().mean().item() < 3e-3

@@ -197,11 +197,16 @@ def main():
         return select_detections(classes[-1].float(), coords[-1].float(), t[3 * L])
 
     flat_inputs = [*feats, *masks, *pos, sizes]
-    if args.no_graph:
-        run = forward
-    else:                                                   # same kernels, one hipGraph launch per batch (graph.py)
+    launch = "python"
+    run = forward
+    if not args.no_graph:                                   # same kernels, one hipGraph launch per batch (graph.py)
         from relation_detr_amd.graph import GraphedCall
-        run = GraphedCall(forward, flat_inputs)
+        try:
+            run = GraphedCall(forward, flat_inputs)
+            launch = "hipGraph replay"
+        except RuntimeError as e:                           # capture refused by the runtime: enqueue from Python instead
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {str(e)[:200]}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
 
     def step():
         dets = run(*flat_inputs)
@@ -239,7 +244,7 @@ def main():
                                    "layers (MSDA self-attn, S=22323) + two-stage top-k + 6 decoder layers (relation-biased "
                                    "self-attn + MSDA cross-attn + box refinement) + top-300 detections; backbone/neck excluded",
                        "batch_per_gpu": B, "global_batch": B * world, "queries": Nq, "levels": 4,
-                       "launch": "python" if args.no_graph else "hipGraph replay",
+                       "launch": launch,
                        "parallelism": f"image-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_qrun_kernel (encoder shape, B=%d)" % B,
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

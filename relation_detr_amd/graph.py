@@ -34,7 +34,9 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph), torch.no_grad():
+        # thread_local: other threads of the process (the RCCL watchdog of an initialised process group polls events)
+        # must not invalidate the capture
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), torch.no_grad():
             self._outputs = fn(*self._inputs)
 
     def __call__(self, *inputs: torch.Tensor):

@@ -206,6 +206,15 @@ int rdetr_add_layernorm_f32(const float *x, const float *residual, const float *
                             long long rows, int C, float eps, float *out, void *stream);
 int rdetr_add_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma, const uint16_t *beta,
                              long long rows, int C, float eps, uint16_t *out, void *stream);
+/* Same with row strides in ELEMENTS (ldx, ldr, ldo >= C): inputs / output may be column slices of wider matrices -- the
+ * encoder writes each layer's output straight into its slice of the [rows, 7*C] memory-fusion input
+ * (relation_transformer.py:196-214) instead of concatenating afterwards. */
+int rdetr_add_layernorm_strided_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                                    long long rows, int C, long long ldx, long long ldr, long long ldo, float eps,
+                                    float *out, void *stream);
+int rdetr_add_layernorm_strided_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma,
+                                     const uint16_t *beta, long long rows, int C, long long ldx, long long ldr,
+                                     long long ldo, float eps, uint16_t *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,8 @@ SIGNATURES = {
     "rdetr_relation_attention_bf16": [_vp] * 3 + [_c_int] * 3 + [_vp, _vp] + [_c_int] * 5 + [_c_float, _vp, _c_int, _vp],
     "rdetr_add_layernorm_f32": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
     "rdetr_add_layernorm_bf16": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
+    "rdetr_add_layernorm_strided_f32": [_vp] * 4 + [_c_ll, _c_int, _c_ll, _c_ll, _c_ll, _c_float, _vp, _vp],
+    "rdetr_add_layernorm_strided_bf16": [_vp] * 4 + [_c_ll, _c_int, _c_ll, _c_ll, _c_ll, _c_float, _vp, _vp],
 }
 
 _lib = None

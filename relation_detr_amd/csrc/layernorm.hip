@@ -58,16 +58,17 @@ template <typename T>
 __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm256_kernel(const T *__restrict__ x, const T *__restrict__ r,
                                                                            const T *__restrict__ gamma,
                                                                            const T *__restrict__ beta, long long rows,
+                                                                           long long ldx, long long ldr, long long ldo,
                                                                            float eps, T *__restrict__ out)
 {
     const long long row = (long long)blockIdx.x * kLnWaves + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int c = (threadIdx.x & 63) * 4;
     float v[4], g[4], b[4];
-    LnIO<T>::load4(x + row * 256 + c, v);
+    LnIO<T>::load4(x + row * ldx + c, v);
     if (r) {
         float t[4];
-        LnIO<T>::load4(r + row * 256 + c, t);
+        LnIO<T>::load4(r + row * ldr + c, t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] += t[i];
     }
@@ -84,19 +85,20 @@ __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm256_kernel(const
     float y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = d[i] * rstd * g[i] + b[i];
-    LnIO<T>::store4(out + row * 256 + c, y);
+    LnIO<T>::store4(out + row * ldo + c, y);
 }
 
 template <typename T>
 __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm_generic_kernel(const T *__restrict__ x, const T *__restrict__ r,
                                                                                 const T *__restrict__ gamma,
                                                                                 const T *__restrict__ beta, long long rows,
-                                                                                int C, float eps, T *__restrict__ out)
+                                                                                int C, long long ldx, long long ldr,
+                                                                                long long ldo, float eps, T *__restrict__ out)
 {
     const long long row = (long long)blockIdx.x * kLnWaves + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const T *xr = x + row * C, *rr = r ? r + row * C : nullptr;
+    const T *xr = x + row * ldx, *rr = r ? r + row * ldr : nullptr;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += LnIO<T>::load1(xr + c) + (rr ? LnIO<T>::load1(rr + c) : 0.f);
     const float mean = ln_wave_sum(s) / (float)C;
@@ -108,26 +110,28 @@ __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm_generic_kernel(
     const float rstd = 1.0f / sqrtf(ln_wave_sum(sq) / (float)C + eps);
     for (int c = lane; c < C; c += 64) {
         const float d = LnIO<T>::load1(xr + c) + (rr ? LnIO<T>::load1(rr + c) : 0.f) - mean;
-        LnIO<T>::store1(out + row * C + c, d * rstd * LnIO<T>::load1(gamma + c) + LnIO<T>::load1(beta + c));
+        LnIO<T>::store1(out + row * ldo + c, d * rstd * LnIO<T>::load1(gamma + c) + LnIO<T>::load1(beta + c));
     }
 }
 
 template <typename T>
-static int add_layernorm(const T *x, const T *r, const T *gamma, const T *beta, long long rows, int C, float eps, T *out,
-                         hipStream_t stream)
+static int add_layernorm(const T *x, const T *r, const T *gamma, const T *beta, long long rows, int C, long long ldx,
+                         long long ldr, long long ldo, float eps, T *out, hipStream_t stream)
 {
-    if (rows < 0 || C <= 0 || C > 8192) return RDETR_ERR_INVALID_ARG;
+    if (rows < 0 || C <= 0 || C > 8192 || ldx < C || ldo < C || (r && ldr < C)) return RDETR_ERR_INVALID_ARG;
     if (rows == 0) return RDETR_OK;
     if (!x || !gamma || !beta || !out) return RDETR_ERR_INVALID_ARG;
     const long long nblk = (rows + kLnWaves - 1) / kLnWaves;
     if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
     auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    if (C == 256 && al16(x) && al16(out) && al16(gamma) && al16(beta) && (!r || al16(r)))
+    const long long a16 = 16 / (long long)sizeof(T);
+    if (C == 256 && al16(x) && al16(out) && al16(gamma) && al16(beta) && (!r || al16(r)) && ldx % a16 == 0 && ldo % a16 == 0 &&
+        (!r || ldr % a16 == 0))
         hipLaunchKernelGGL((add_layernorm256_kernel<T>), dim3((unsigned)nblk), dim3(kLnWaves * kWave), 0, stream, x, r, gamma,
-                           beta, rows, eps, out);
+                           beta, rows, ldx, ldr, ldo, eps, out);
     else
         hipLaunchKernelGGL((add_layernorm_generic_kernel<T>), dim3((unsigned)nblk), dim3(kLnWaves * kWave), 0, stream, x, r,
-                           gamma, beta, rows, C, eps, out);
+                           gamma, beta, rows, C, ldx, ldr, ldo, eps, out);
     return launch_status();
 }
 
@@ -136,11 +140,26 @@ static int add_layernorm(const T *x, const T *r, const T *gamma, const T *beta, 
 extern "C" int rdetr_add_layernorm_f32(const float *x, const float *residual, const float *gamma, const float *beta,
                                        long long rows, int C, float eps, float *out, void *stream)
 {
-    return rdetr::add_layernorm<float>(x, residual, gamma, beta, rows, C, eps, out, static_cast<hipStream_t>(stream));
+    return rdetr::add_layernorm<float>(x, residual, gamma, beta, rows, C, C, C, C, eps, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_add_layernorm_strided_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                                               long long rows, int C, long long ldx, long long ldr, long long ldo, float eps,
+                                               float *out, void *stream)
+{
+    return rdetr::add_layernorm<float>(x, residual, gamma, beta, rows, C, ldx, ldr, ldo, eps, out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rdetr_add_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma,
                                         const uint16_t *beta, long long rows, int C, float eps, uint16_t *out, void *stream)
 {
-    return rdetr::add_layernorm<uint16_t>(x, residual, gamma, beta, rows, C, eps, out, static_cast<hipStream_t>(stream));
+    return rdetr::add_layernorm<uint16_t>(x, residual, gamma, beta, rows, C, C, C, C, eps, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_add_layernorm_strided_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma,
+                                                const uint16_t *beta, long long rows, int C, long long ldx, long long ldr,
+                                                long long ldo, float eps, uint16_t *out, void *stream)
+{
+    return rdetr::add_layernorm<uint16_t>(x, residual, gamma, beta, rows, C, ldx, ldr, ldo, eps, out,
+                                          static_cast<hipStream_t>(stream));
 }

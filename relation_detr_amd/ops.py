@@ -317,11 +317,27 @@ def bias_softmax_(scores: torch.Tensor, bias: Optional[torch.Tensor] = None,
     return scores
 
 
+def _row_matrix(t: torch.Tensor):
+    """(tensor, row stride) if `t` is a [.., C] tensor whose rows are evenly strided with a contiguous last dim (a
+    contiguous tensor or a column slice of one); else a contiguous copy."""
+    C = t.shape[-1]
+    if t.stride(-1) == 1 and t.dim() >= 1:
+        ld = t.stride(-2) if t.dim() >= 2 else C
+        ok = ld >= C
+        for d in range(t.dim() - 3, -1, -1):                  # outer dims must continue the same row pitch
+            ok = ok and (t.shape[d] == 1 or t.stride(d) == t.stride(d + 1) * t.shape[d + 1])
+        if ok:
+            return t, ld
+    t = t.contiguous()
+    return t, C
+
+
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
-                   eps: float = 1e-5) -> torch.Tensor:
-    """LayerNorm(x + residual) over the last dimension in one pass (fp32 / bf16; residual may be None).
+                   eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(x + residual) over the last dimension in one pass (fp32 / bf16; residual may be None).  `x`,
+    `residual` and `out` may be column slices of wider row-major tensors (evenly strided rows).
     Inference-only (no autograd): the harness uses it under torch.no_grad()."""
-    _require_device(x, residual, weight, bias)
+    _require_device(x, residual, weight, bias, out)
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise _lib.RdetrError(f"add_layer_norm: dtype {x.dtype} not supported (float32 or bfloat16)")
     C = x.shape[-1]
@@ -329,13 +345,22 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
         raise _lib.RdetrError("add_layer_norm: residual must have x's shape and dtype")
     if weight.numel() != C or bias.numel() != C:
         raise _lib.RdetrError("add_layer_norm: weight / bias must have C elements")
-    x = x.contiguous()
-    residual = None if residual is None else residual.contiguous()
+    x, ldx = _row_matrix(x)
+    ldr = C
+    if residual is not None:
+        residual, ldr = _row_matrix(residual)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    elif out.shape != x.shape or out.dtype != x.dtype:
+        raise _lib.RdetrError("add_layer_norm: out must have x's shape and dtype")
+    o, ldo = _row_matrix(out)
+    if o is not out:
+        raise _lib.RdetrError("add_layer_norm: out must have evenly strided rows with a contiguous last dimension")
     w, b = weight.detach().to(x.dtype).contiguous(), bias.detach().to(x.dtype).contiguous()
-    out = torch.empty_like(x)
-    fn = _lib.load().rdetr_add_layernorm_f32 if x.dtype == torch.float32 else _lib.load().rdetr_add_layernorm_bf16
+    lib = _lib.load()
+    fn = lib.rdetr_add_layernorm_strided_f32 if x.dtype == torch.float32 else lib.rdetr_add_layernorm_strided_bf16
     st = fn(x.data_ptr(), None if residual is None else residual.data_ptr(), w.data_ptr(), b.data_ptr(),
-            x.numel() // C, C, float(eps), out.data_ptr(), _stream_ptr(x))
+            x.numel() // C, C, ldx, ldr, ldo, float(eps), out.data_ptr(), _stream_ptr(x))
     _lib.check(st, "rdetr_add_layernorm")
     return out
 

@@ -47,15 +47,19 @@ def sine_pos_embed(pos: Tensor, num_pos_feats: int = 128, temperature: float = 1
     return torch.cat((emb[..., 1:2, :], emb[..., 0:1, :], emb[..., 2:, :]), dim=-2).flatten(-2)
 
 
-def add_norm(norm: nn.LayerNorm, x: Tensor, residual: Tensor = None) -> Tensor:
+def add_norm(norm: nn.LayerNorm, x: Tensor, residual: Tensor = None, out: Tensor = None) -> Tensor:
     """norm(x + residual).  On a ROCm device without autograd: one HIP kernel (rdetr_add_layernorm_*, csrc/layernorm.hip)
     instead of an add pass and a normalisation pass; otherwise (CPU oracle harness, training) plain torch."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or norm.weight.requires_grad or
                                               (residual is not None and residual.requires_grad))
     if x.is_cuda and not needs_grad and x.dtype in (torch.float32, torch.bfloat16):
         from . import ops
-        return ops.add_layer_norm(x, residual, norm.weight, norm.bias, norm.eps)
-    return norm(x if residual is None else x + residual)
+        return ops.add_layer_norm(x, residual, norm.weight, norm.bias, norm.eps, out=out)
+    y = norm(x if residual is None else x + residual)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def linear_relu(linear: nn.Linear, x: Tensor) -> Tensor:
@@ -97,12 +101,13 @@ class RelationTransformerEncoderLayer(nn.Module):
         nn.init.xavier_uniform_(self.linear1.weight)
         nn.init.xavier_uniform_(self.linear2.weight)
 
-    def forward(self, query, query_pos, reference_points, spatial_shapes, level_start_index, key_padding_mask=None):
+    def forward(self, query, query_pos, reference_points, spatial_shapes, level_start_index, key_padding_mask=None, out=None):
+        """`out`: optional destination of the layer's output (a column slice of the encoder's memory-fusion input)."""
         attn = self.self_attn(query=query if query_pos is None else query + query_pos, reference_points=reference_points,
                               value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               key_padding_mask=key_padding_mask)
         query = add_norm(self.norm1, query, attn)
-        return add_norm(self.norm2, query, self.linear2(linear_relu(self.linear1, query)))
+        return add_norm(self.norm2, query, self.linear2(linear_relu(self.linear1, query)), out=out)
 
 
 class RelationTransformerEncoder(nn.Module):
@@ -118,11 +123,23 @@ class RelationTransformerEncoder(nn.Module):
                                            nn.LayerNorm(d))
 
     def forward(self, query, spatial_shapes, level_start_index, reference_points, query_pos=None, query_key_padding_mask=None):
+        fuse = self.memory_fusion
+        if query.is_cuda and not torch.is_grad_enabled():
+            # inference: every layer writes its output straight into its column slice of the fusion input (the
+            # reference concatenates the 7 tensors afterwards, relation_transformer.py:212); the slices are then
+            # the next layer's input as strided views
+            d = self.embed_dim
+            stacked = torch.empty(*query.shape[:-1], (self.num_layers + 1) * d, dtype=query.dtype, device=query.device)
+            stacked[..., :d].copy_(query)
+            query = stacked[..., :d]
+            for i, layer in enumerate(self.layers):
+                query = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask,
+                              out=stacked[..., (i + 1) * d:(i + 2) * d])
+            return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], stacked)))
         outs = [query]
         for layer in self.layers:
             query = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask)
             outs.append(query)
-        fuse = self.memory_fusion
         return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], torch.cat(outs, -1))))
 
 
@@ -298,8 +315,9 @@ class RelationTransformer(nn.Module):
         valid = ((proposals > 0.01) & (proposals < 0.99)).all(-1, keepdim=True)
         logit = torch.log(proposals / (1 - proposals))
         logit = logit.masked_fill(padding_mask.unsqueeze(-1) | ~valid, float("inf"))
-        out = memory * (~padding_mask.unsqueeze(-1)) * valid
-        return self.enc_output_norm(self.enc_output(out)), logit
+        keep = (~padding_mask.unsqueeze(-1)) & valid                                 # one pass over memory instead of two
+        out = memory * keep.to(memory.dtype)
+        return add_norm(self.enc_output_norm, self.enc_output(out)), logit
 
     def forward(self, multi_level_feats: Sequence[Tensor], multi_level_masks: Sequence[Tensor],
                 multi_level_pos_embeds: Sequence[Tensor]):

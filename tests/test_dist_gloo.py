@@ -74,5 +74,15 @@ def test_gather_detections_rccl_single_rank():
         torch.cuda.synchronize()
         assert out_d.shape == (4, 300, 6) and torch.equal(out_d, d) and torch.equal(out_i, i)
         dist.barrier()
+        # bench.py's multi-GPU step: HIP-graph capture + replay while the RCCL process group (and its watchdog
+        # thread) is alive, then the gather of the replayed detections
+        from relation_detr_amd.graph import GraphedCall
+        lin = torch.nn.Linear(6, 6).to("cuda:0")
+        run = GraphedCall(lambda t: lin(t).relu(), [d])
+        eager = lin(d).relu()
+        for _ in range(3):
+            got, _ = gather_detections(run(d), i)
+        torch.cuda.synchronize()
+        assert torch.allclose(got, eager)
     finally:
         dist.destroy_process_group()

@@ -164,3 +164,22 @@ def test_self_attention_module_fused_path_matches_unfused():
     unfused = mod(xg + pos, xg + pos, xg, attn_mask=bias)[0].float().detach()
     assert (fused - unfused).abs().max().item() < 3e-2
     assert (fused - unfused).abs().mean().item() < 3e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_add_layer_norm_column_slices(dtype):
+    """x, residual and out as column slices of wider matrices (the encoder's memory-fusion layout)."""
+    from relation_detr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    wide = torch.randn(3, 50, 7 * 256, generator=g).to(dtype).to(DEV)
+    res_wide = torch.randn(3, 50, 512, generator=g).to(dtype).to(DEV)
+    out_wide = torch.zeros(3, 50, 7 * 256, dtype=dtype, device=DEV)
+    w = (1 + 0.1 * torch.randn(256, generator=g)).to(dtype).to(DEV)
+    b = (0.1 * torch.randn(256, generator=g)).to(dtype).to(DEV)
+    x, r, o = wide[..., 256:512], res_wide[..., 256:], out_wide[..., 1024:1280]
+    got = ops.add_layer_norm(x, r, w, b, 1e-5, out=o)
+    assert got.data_ptr() == o.data_ptr()
+    ref = F.layer_norm(x.float() + r.float(), (256,), w.float(), b.float(), 1e-5)
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert (o.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert out_wide[..., :1024].abs().max().item() == 0 and out_wide[..., 1280:].abs().max().item() == 0   # nothing else touched

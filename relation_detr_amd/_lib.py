@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librelation_detr_amd.so")
+LIB_PATH = os.environ.get("RDETR_LIB_PATH") or os.path.join(_HERE, "librelation_detr_amd.so")    # override: A/B builds
 
 _c_int, _c_float, _vp, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 

@@ -6,8 +6,8 @@
 // FMAs cost 3 instructions per sample).  This kernel removes both:
 //   memory   per SPATIAL tile (a 16 x 12 pixel region of level 0 and the pixels of the coarser levels whose centres fall
 //            into it: <= 192 + 64 queries) and per sampled level, the window ("rect") of the value plane the tile's
-//            queries sample -- the bounding box of their ACTUAL sample corners, clipped to the buffer -- is copied
-//            L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, coalesced, no VGPRs) one pass ahead of its use.  Tiles are
+//            queries sample -- the region's footprint in that level grown to a fixed size (+-11 x +-8 pixels around a
+//            region at level 0) -- is copied L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, coalesced, no VGPRs) one pass ahead of its use.  Tiles are
 //            spatial so that every query level of a region shares one window per sampled level (a 16 x 16 block of
 //            level-2 QUERIES would need a 64 x 64 window of level 0).
 //   math     the bilinear gather-and-weighted-sum runs on the matrix cores: v_mfma_f32_16x16x32_bf16 with
@@ -25,14 +25,14 @@
 //
 //   workgroup = 1024 threads = 16 waves, persistent over a contiguous range of the tiles of ONE (image, head);
 //               waves 0..11 own the 12 rows of the region's level-0 pixels, waves 12..15 its coarser-level pixels
-//   LDS 160 KiB = 2 KiB tables | 16 x 2 KiB per-wave staging (row offsets + bf16 weights; re-used as the patch and as the
-//               output transpose) | buffer A 1344 px | buffer B 672 px  (64 B / pixel = one bf16 head row)
+//   LDS 160 KiB = 3 KiB tables | 16 x 2 KiB per-wave staging (row offsets + bf16 weights; re-used as the patch and as the
+//               output transpose) | buffer A 1344 px | buffer B 656 px  (64 B / pixel = one bf16 head row)
 //   passes    = one per sampled level, order L0 (A), L2 (B), L1 (A), L3 (B): the buffers alternate, the DMA of the next
-//               pass is issued before the MFMA loop of the current one; the next tile's locations are loaded and their
-//               bounding boxes reduced two passes ahead.  One barrier per pass.
+//               pass is issued before the MFMA loop of the current one; the next tile's locations are loaded one tile
+//               ahead.  One barrier per pass.
 // Per corner the arithmetic is msda_fwd.hip's (same weights, same zero padding); the summation order differs and each
 // weight carries a 2^-17 relative representation error (the bf16 output rounds at 2^-9).
-#include <climits>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -49,15 +49,17 @@ constexpr int kTlCoarseSlots = (kTlWaves - kTlCoarseWave0) * 16;
 constexpr int kTlHeads = 8, kTlHeadDim = 32, kTlPoints = 4, kTlLevels = 4;
 constexpr unsigned kTlPixB = 64;                              // LDS bytes per pixel (one bf16 head row)
 constexpr unsigned kTlGPixB = kTlHeads * kTlHeadDim * 2;      // global bytes per pixel (512)
-constexpr int kTlMiscBytes = 2048;
-constexpr int kTlZeroOff = 512;                               // 64 zero bytes (inside the misc area)
+constexpr int kTlMiscBytes = 3072;
+constexpr int kTlZeroOff = 512;                               // 64 zero bytes (inside the misc area): the "zero row"
 constexpr int kTlFgoOff = 1024;                               // 16 waves x 64 B: global row offsets of the flagged samples in flight
+constexpr int kTlZeroKOff = 2048 + 32;                        // ~1 KiB of zeros (from 2048): what the idle lanes of an A operand read;
+                                                              // == 32 (mod 256) keeps it off the banks of the active lanes' weights
 constexpr int kTlStageOff = kTlMiscBytes;
 constexpr int kTlStagePerWave = 2048;                         // [0,1K) row offsets O[query][point][corner], [1K,2K) weights
 constexpr int kTlBufAOff = kTlStageOff + kTlWaves * kTlStagePerWave;
-constexpr int kTlCapA = 1344, kTlSqWA = 42, kTlSqHA = 32;     // pixels; fallback rect of the buffer when both sides clip
+constexpr int kTlCapA = 1344, kTlSqWA = 38, kTlSqHA = 28;     // buffer capacity in pixels; window of level 0 (level 1: 30 x 28)
 constexpr int kTlBufBOff = kTlBufAOff + kTlCapA * (int)kTlPixB;
-constexpr int kTlCapB = 672, kTlSqWB = 26, kTlSqHB = 25;
+constexpr int kTlCapB = 656, kTlSqWB = 22, kTlSqHB = 21;      // window of levels 2 / 3 (a level that fits is taken whole)
 constexpr int kTlLdsBytes = kTlBufBOff + kTlCapB * (int)kTlPixB;
 static_assert(kTlLdsBytes == 160 * 1024, "LDS map must fill exactly 160 KiB");
 
@@ -65,7 +67,7 @@ struct TileShared {
     int h[kTlLevels], w[kTlLevels], start[kTlLevels];
     int regions_x, regions_y, chunks;      // spatial tiles of level 0; coarse-query chunks per region (1 unless > 64 coarse)
     int max_coarse;
-    int bbox[kTlLevels * 4];               // per level: min x, min y, max x, max y of the next tile's valid sample corners
+    int geo[2][20];                        // per tile parity: rx, ry, chunk, -, then per coarser level: xa, ya, nx, n, 2^16 / nx
     int desc[2][kTlLevels][4];             // per tile parity and level: rect x, y, width (== 2 mod 4), height (0 = none)
 };
 static_assert(sizeof(TileShared) <= kTlZeroOff, "tables overlap the zero row");
@@ -75,24 +77,6 @@ struct TileSamples {                       // lane (query = lane >> 2, point = l
     float a[kTlLevels];
     int q;                                 // query index of lane >> 2, -1 = none
 };
-
-template <bool MAX> __device__ __forceinline__ int tl_wave_reduce(int v)
-{
-#define RDETR_TL_STEP(ctrl)                                                          \
-    {                                                                                \
-        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);      \
-        v = MAX ? (v > o ? v : o) : (v < o ? v : o);                                 \
-    }
-    RDETR_TL_STEP(0xB1)     // quad_perm [1,0,3,2]
-    RDETR_TL_STEP(0x4E)     // quad_perm [2,3,0,1]
-    RDETR_TL_STEP(0x141)    // row_half_mirror
-    RDETR_TL_STEP(0x140)    // row_mirror
-#undef RDETR_TL_STEP
-    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    const int ab = MAX ? (a > b ? a : b) : (a < b ? a : b), cd = MAX ? (c > d ? c : d) : (c < d ? c : d);
-    return MAX ? (ab > cd ? ab : cd) : (ab < cd ? ab : cd);
-}
 
 __device__ __forceinline__ float tl_quad_max(float v)
 {
@@ -134,28 +118,42 @@ __device__ __forceinline__ TileCorner tl_corners(f32x2 xy, float a, bool qok, in
     return c;
 }
 
+// a / b for a < 2^24, 0 < b < 2^24, without the ~40-instruction integer division sequence: the float quotient is within
+// one of the exact one, two compare-and-adjust steps fix it
+__device__ __forceinline__ unsigned tl_div(unsigned a, unsigned b)
+{
+    unsigned q = (unsigned)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int r = (int)a - (int)(q * b);
+    if (r < 0) { --q; r += (int)b; }
+    if (r >= (int)b) { ++q; }
+    return q;
+}
+
 // first pixel coordinate of a level of size `n` whose centre lies in region `r` or beyond (regions of `reg` level-0
 // pixels, level-0 size n0): the smallest x with (2x + 1) * n0 >= 2 * reg * n * r, clipped to n
 __device__ __forceinline__ int tl_region_begin(int r, int reg, int n, int n0)
 {
-    const long long v = 2ll * reg * n * r;
-    const int c = (int)((v + n0 - 1) / n0);
-    const int x = c / 2;
+    const unsigned v = 2u * (unsigned)reg * (unsigned)n * (unsigned)r;      // < 2^24: checked on the host
+    const unsigned c = tl_div(v + (unsigned)n0 - 1u, (unsigned)n0);
+    const int x = (int)(c >> 1);
     return x < n ? x : n;
 }
 
-// bf16 high part (round to nearest even) and low part of an fp32 weight: w = hi + lo up to 2^-17 |w|
-__device__ __forceinline__ void tl_split(float w, unsigned &hi, unsigned &lo)
+// bf16 high parts (round to nearest even) and low parts of two fp32 weights, packed (a in the low half):
+// w = hi + lo up to 2^-17 |w|
+typedef __bf16 tl_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tl_split2(float a, float b, unsigned &hi, unsigned &lo)
 {
-    hi = f32_to_bf16_bits(w);
-    lo = f32_to_bf16_bits(w - bf16_bits_to_f32(hi));
+    hi = __builtin_bit_cast(unsigned, tl_bf16x2{(__bf16)a, (__bf16)b});
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, tl_bf16x2{(__bf16)ra, (__bf16)rb});
 }
 
 template <bool FUSED>
 __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     const uint16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
-    int splits, int nblk, uint16_t *__restrict__ out)
+    int splits, int nblk, int dbg, int rect_cfg, uint16_t *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     TileShared &sh = *reinterpret_cast<TileShared *>(lds);
@@ -174,8 +172,8 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         sh.regions_y = (sh.h[0] + kTlRegH - 1) / kTlRegH;
         sh.max_coarse = 0;
     }
-    if (tid < kTlLevels * 4) sh.bbox[tid] = (tid & 2) ? INT_MIN : INT_MAX;
     if (tid < 16) reinterpret_cast<unsigned *>(lds + kTlZeroOff)[tid] = 0u;
+    if (tid < 256) reinterpret_cast<unsigned *>(lds + 2048)[tid] = 0u;
     __syncthreads();
 
     // coarser-level pixels per region: level l contributes [xa, xb) x [ya, yb), the pixels whose centres fall in the region
@@ -203,11 +201,23 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     if (tid == 0) sh.chunks = sh.max_coarse <= kTlCoarseSlots ? 1 : (sh.max_coarse + kTlCoarseSlots - 1) / kTlCoarseSlots;
     __syncthreads();
 
+    // the tables are wave-uniform: keep them in SGPRs (values read from LDS live in VGPRs, and every index computation
+    // on them -- including the integer divisions of the tile geometry -- would run on the VALU)
+    int LW[kTlLevels], LH[kTlLevels], LS[kTlLevels];
+#pragma unroll
+    for (int l = 0; l < kTlLevels; ++l) {
+        LW[l] = __builtin_amdgcn_readfirstlane(sh.w[l]);
+        LH[l] = __builtin_amdgcn_readfirstlane(sh.h[l]);
+        LS[l] = __builtin_amdgcn_readfirstlane(sh.start[l]);
+    }
+    const int regions_x = __builtin_amdgcn_readfirstlane(sh.regions_x);
+    const int regions_y = __builtin_amdgcn_readfirstlane(sh.regions_y);
+
     const int logical = xcd_contiguous_block(blockIdx.x, nblk);
     const int pair = logical / splits, split = logical - pair * splits;
     const int b = pair / kTlHeads, m = pair - b * kTlHeads;
-    const int chunks = sh.chunks;
-    const int ntiles = sh.regions_x * sh.regions_y * chunks;
+    const int chunks = __builtin_amdgcn_readfirstlane(sh.chunks);
+    const int ntiles = regions_x * regions_y * chunks;
     const int t0 = (int)((long long)split * ntiles / splits), t1 = (int)((long long)(split + 1) * ntiles / splits);
     if (t0 >= t1) return;                                   // uniform for the workgroup
 
@@ -221,33 +231,60 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
     const int am = lane & 15, ar = am & 3;
     const bool a_active = (am >> 2) == g;
-    const unsigned a_mlo = (a_active && !(ar & 1)) ? 0xffffffffu : 0u, a_mhi = (a_active && (ar & 1)) ? 0xffffffffu : 0u;
     const unsigned stage_off = (unsigned)(kTlStageOff + wave * kTlStagePerWave);
     unsigned char *stage = lds + stage_off;
     const unsigned o_rd = stage_off + (unsigned)(g * 128 + tq * 4);                       // O[2g][.][tq]; + o' * 512 + p * 16
-    const unsigned w_rd = stage_off + 1024u + (unsigned)((2 * g + (ar & 1)) * 64 + (ar >> 1) * 8);
+    // A operand = {low 8 bytes: k = 8g .. 8g+3 (sample 2g), high 8 bytes: k = 8g+4 .. (sample 2g+1)}: an active lane reads
+    // its sample's 4 weights (hi or lo part) into the matching half and zeros into the other; idle lanes read zeros twice
+    const unsigned w_real = stage_off + 1024u + (unsigned)((2 * g + (ar & 1)) * 64 + (ar >> 1) * 8);
+    const unsigned w_rd_lo = (a_active && !(ar & 1)) ? w_real : (unsigned)kTlZeroKOff;
+    const unsigned w_rd_hi = (a_active && (ar & 1)) ? w_real : (unsigned)kTlZeroKOff;
     const unsigned c0 = (unsigned)(tp * 8 + (g & 1) * 32);
     unsigned char *fgo = lds + kTlFgoOff + wave * 64;
 
     // ---- helpers -----------------------------------------------------------------------------------------------
     // query owned by lane >> 2 of this wave in tile t (-1 = none)
+    // Tile geometry (which region, and which pixels of the coarser levels have their centres in it) costs a dozen integer
+    // divisions: ONE lane per value computes it, once per tile, into sh.geo[t & 1]; every wave then reads it as scalars.
+    auto compute_geometry = [&](int t, int k) {        // k = lane of the computing wave, 0 .. 15
+        const int region = (int)tl_div((unsigned)t, (unsigned)chunks), chunk = t - region * chunks;
+        const int ry = (int)tl_div((unsigned)region, (unsigned)regions_x), rx = region - ry * regions_x;
+        int *geo = sh.geo[t & 1];
+        if (k == 0) { geo[0] = rx; geo[1] = ry; geo[2] = chunk; }
+        if (k >= 1 && k < kTlLevels) {
+            const int l = k;
+            const int xa = tl_region_begin(rx, kTlRegW, LW[l], LW[0]), xb = tl_region_begin(rx + 1, kTlRegW, LW[l], LW[0]);
+            const int ya = tl_region_begin(ry, kTlRegH, LH[l], LH[0]), yb = tl_region_begin(ry + 1, kTlRegH, LH[l], LH[0]);
+            const int nx = xb - xa;
+            geo[4 + 5 * (l - 1) + 0] = xa;
+            geo[4 + 5 * (l - 1) + 1] = ya;
+            geo[4 + 5 * (l - 1) + 2] = nx;
+            geo[4 + 5 * (l - 1) + 3] = nx * (yb - ya);
+            geo[4 + 5 * (l - 1) + 4] = nx > 0 ? (int)tl_div(65536u + (unsigned)nx - 1u, (unsigned)nx) : 0;   // j / nx for j < 2^16 / nx
+        }
+    };
+
+    // query owned by lane >> 2 of this wave in tile t (-1 = none)
     auto query_of = [&](int t) -> int {
-        const int region = t / chunks, chunk = t - region * chunks;
-        const int ry = region / sh.regions_x, rx = region - ry * sh.regions_x;
+        const int *geo = sh.geo[t & 1];
+        const int rx = __builtin_amdgcn_readfirstlane(geo[0]), ry = __builtin_amdgcn_readfirstlane(geo[1]);
+        const int chunk = __builtin_amdgcn_readfirstlane(geo[2]);
         if (wave < kTlCoarseWave0) {
             const int x = rx * kTlRegW + qx, y = ry * kTlRegH + wave;
-            return (chunk == 0 && x < sh.w[0] && y < sh.h[0]) ? sh.start[0] + y * sh.w[0] + x : -1;
+            return (chunk == 0 && x < LW[0] && y < LH[0]) ? LS[0] + y * LW[0] + x : -1;
         }
         int j = chunk * kTlCoarseSlots + (wave - kTlCoarseWave0) * 16 + qx;
         int q = -1;
 #pragma unroll
         for (int l = 1; l < kTlLevels; ++l) {
-            const int xa = tl_region_begin(rx, kTlRegW, sh.w[l], sh.w[0]), xb = tl_region_begin(rx + 1, kTlRegW, sh.w[l], sh.w[0]);
-            const int ya = tl_region_begin(ry, kTlRegH, sh.h[l], sh.h[0]), yb = tl_region_begin(ry + 1, kTlRegH, sh.h[l], sh.h[0]);
-            const int nx = xb - xa, n = nx * (yb - ya);
+            const int xa = __builtin_amdgcn_readfirstlane(geo[4 + 5 * (l - 1) + 0]);
+            const int ya = __builtin_amdgcn_readfirstlane(geo[4 + 5 * (l - 1) + 1]);
+            const int nx = __builtin_amdgcn_readfirstlane(geo[4 + 5 * (l - 1) + 2]);
+            const int n = __builtin_amdgcn_readfirstlane(geo[4 + 5 * (l - 1) + 3]);
+            const unsigned inv = (unsigned)__builtin_amdgcn_readfirstlane(geo[4 + 5 * (l - 1) + 4]);
             if (q < 0 && j >= 0 && j < n) {
-                const int yy = j / nx;
-                q = sh.start[l] + (ya + yy) * sh.w[l] + xa + (j - yy * nx);
+                const int yy = (int)(((unsigned)j * inv) >> 16);
+                q = LS[l] + (ya + yy) * LW[l] + xa + (j - yy * nx);
             }
             j -= n;
         }
@@ -284,8 +321,8 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
                 const float *rp = ref + (row * kTlLevels + l) * (size_t)ref_dim;
                 sm.a[l] = sm.a[l] / sum;
                 if (ref_dim == 2) {
-                    sm.xy[l].x = rp[0] + sm.xy[l].x / (float)sh.w[l];
-                    sm.xy[l].y = rp[1] + sm.xy[l].y / (float)sh.h[l];
+                    sm.xy[l].x = rp[0] + sm.xy[l].x / (float)LW[l];
+                    sm.xy[l].y = rp[1] + sm.xy[l].y / (float)LH[l];
                 } else {
                     sm.xy[l].x = rp[0] + sm.xy[l].x * (1.0f / kTlPoints) * rp[2] * 0.5f;
                     sm.xy[l].y = rp[1] + sm.xy[l].y * (1.0f / kTlPoints) * rp[3] * 0.5f;
@@ -303,51 +340,41 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         }
     };
 
-    // bounding box, per level, of the pixels the tile's valid sample corners touch -> LDS atomics
-    auto bbox_accumulate = [&](const TileSamples &sm) {
-#pragma unroll
-        for (int l = 0; l < kTlLevels; ++l) {
-            const TileCorner c = tl_corners(sm.xy[l], sm.a[l], sm.q >= 0, sh.w[l], sh.h[l]);
-            const int mnx = tl_wave_reduce<false>(c.inside ? c.xa : INT_MAX);
-            const int mny = tl_wave_reduce<false>(c.inside ? c.ya : INT_MAX);
-            const int mxx = tl_wave_reduce<true>(c.inside ? c.xb : INT_MIN);
-            const int mxy = tl_wave_reduce<true>(c.inside ? c.yb : INT_MIN);
-            if (lane == 0 && mxx >= mnx) {
-                atomicMin(&sh.bbox[l * 4 + 0], mnx);
-                atomicMin(&sh.bbox[l * 4 + 1], mny);
-                atomicMax(&sh.bbox[l * 4 + 2], mxx);
-                atomicMax(&sh.bbox[l * 4 + 3], mxy);
-            }
+    // thread l: the window of level l for tile t = the region's footprint in that level (the pixels whose centres lie in
+    // it) grown symmetrically to a fixed size: 38 x 28 / 30 x 28 in A (levels 0 / 1: +-11 x +-8 pixels around a region), 22 x 21
+    // in B (levels 2 / 3; a level that fits entirely is taken whole) -- the sizes that measured fastest on SURVEY 8d's spread.  Fixed-size windows cost nothing to determine (a
+    // data-driven bounding box per tile was a quarter of the kernel's time and came out clipped to these sizes anyway);
+    // whatever a window misses is flagged and patched, so this is a speed heuristic only.
+    auto fixed_desc = [&](int l, int t) {
+        const int *geo = sh.geo[t & 1];
+        int fx0, fx1, fy0, fy1;                        // footprint [fx0, fx1) x [fy0, fy1)
+        if (l == 0) {
+            fx0 = geo[0] * kTlRegW; fx1 = fx0 + kTlRegW;
+            fy0 = geo[1] * kTlRegH; fy1 = fy0 + kTlRegH;
+        } else {
+            const int nx = geo[4 + 5 * (l - 1) + 2], n = geo[4 + 5 * (l - 1) + 3];
+            fx0 = geo[4 + 5 * (l - 1)]; fx1 = fx0 + nx;
+            fy0 = geo[4 + 5 * (l - 1) + 1]; fy1 = fy0 + (nx > 0 ? (int)tl_div((unsigned)n, (unsigned)nx) : 0);
         }
-    };
-
-    // thread l: bounding box of level l -> rect (clipped to the level's buffer), then re-arm the box
-    auto compute_desc = [&](int l, int par) {
-        const int mnx = sh.bbox[l * 4 + 0], mny = sh.bbox[l * 4 + 1], mxx = sh.bbox[l * 4 + 2], mxy = sh.bbox[l * 4 + 3];
-        sh.bbox[l * 4 + 0] = INT_MAX;
-        sh.bbox[l * 4 + 1] = INT_MAX;
-        sh.bbox[l * 4 + 2] = INT_MIN;
-        sh.bbox[l * 4 + 3] = INT_MIN;
-        const bool in_a = l < 2;
-        const int cap = in_a ? kTlCapA : kTlCapB, sqw = in_a ? kTlSqWA : kTlSqWB, sqh = in_a ? kTlSqHA : kTlSqHB;
-        int rx = 0, ry = 0, rw = 2, rh = 0;
-        if (mxx >= mnx) {
-            const int rw0 = mxx - mnx + 1, rh0 = mxy - mny + 1;
-            const int rwp = ((rw0 + 1) & ~3) + 2;              // smallest width >= rw0 that is == 2 (mod 4)
-            rx = mnx; ry = mny; rw = rwp; rh = rh0;
-            if (rwp * rh0 > cap) {
-                if (rh0 <= sqh) rw = (((cap / rh0) - 2) & ~3) + 2;
-                else if (rwp <= sqw) rh = cap / rwp;
-                else { rw = sqw; rh = sqh; }
-                if (rw < rw0) rx = mnx + (rw0 - rw) / 2;
-                if (rh < rh0) ry = mny + (rh0 - rh) / 2;
-                if (rw * rh * 4 < rw0 * rh0) rh = 0;           // would cover < 25 % of the footprint: not worth a fill
-            }
+        const int W = LW[l], H = LH[l];
+        const int cap = l < 2 ? kTlCapA : kTlCapB;
+        int rw = l == 0 ? kTlSqWA : (l == 1 ? kTlSqWA - 8 : kTlSqWB), rh = l < 2 ? kTlSqHA : kTlSqHB;
+        if (rect_cfg) {                                 // tuning aid (RDETR_TILE_RECT): windows grown by 4 * (rect_cfg & 15) columns
+            rw += 4 * (rect_cfg & 15);                  // and (rect_cfg >> 4) rows, as far as the buffers allow
+            rh += rect_cfg >> 4;
+            while (rw * rh > cap) --rh;
         }
-        sh.desc[par][l][0] = rx;
-        sh.desc[par][l][1] = ry;
-        sh.desc[par][l][2] = rw;
-        sh.desc[par][l][3] = rh;
+        const int wfull = ((W + 1) & ~3) + 2;           // smallest width >= W that is == 2 (mod 4)
+        if (wfull <= rw) { rw = wfull; const int hmax = (int)tl_div((unsigned)cap, (unsigned)rw); rh = H < hmax ? H : hmax; }
+        if (H < rh) rh = H;
+        int rx = (fx0 + fx1 - rw) / 2, ry = (fy0 + fy1 - rh) / 2;              // centred on the footprint (floor for negatives is irrelevant: clamped)
+        const int mx = W - rw, my = H - rh;
+        rx = rx > mx ? mx : rx; rx = rx < 0 ? 0 : rx;
+        ry = ry > my ? my : ry; ry = ry < 0 ? 0 : ry;
+        sh.desc[t & 1][l][0] = rx;
+        sh.desc[t & 1][l][1] = ry;
+        sh.desc[t & 1][l][2] = rw;
+        sh.desc[t & 1][l][3] = rh;
     };
 
     // DMA the rect of level l (tile parity par) into its buffer: lane = (pixel, 16-byte chunk), 16 pixels per instruction
@@ -356,19 +383,27 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         const int ry = __builtin_amdgcn_readfirstlane(sh.desc[par][l][1]);
         const int rw = __builtin_amdgcn_readfirstlane(sh.desc[par][l][2]);
         const int rh = __builtin_amdgcn_readfirstlane(sh.desc[par][l][3]);
-        const int W = sh.w[l], st = sh.start[l];
+        const int W = LW[l], st = LS[l];
         const unsigned buf = l < 2 ? (unsigned)kTlBufAOff : (unsigned)kTlBufBOff;
         const int n4 = rw * rh * 4;
-        const float inv = 1.0f / (float)rw;
+        // pixel tid >> 2 of the rect -> (row, column); one division up front (the +0.5 makes the approximate reciprocal
+        // exact for these small integers), then every further pixel of this thread is 256 pixels on: a constant step
+        const float inv = __builtin_amdgcn_rcpf((float)rw);
+        const int r0 = (int)(((float)(tid >> 2) + 0.5f) * inv);
+        int cx = (tid >> 2) - r0 * rw;
+        const int dr = (int)tl_div(256u, (unsigned)rw), dc = 256 - dr * rw;      // uniform
+        int gp = st + (ry + r0) * W + rx + cx;
+        const int step = dr * W + dc, wrap = W - rw;
+        const unsigned lane16 = (unsigned)(tid & 3) * 16u;
         for (int i = tid; i < n4; i += kTlThreads) {
-            const int px = i >> 2, c = i & 3;
-            const int r = (int)(((float)px + 0.5f) * inv);
-            const int cx = px - r * rw;
-            int gp = st + (ry + r) * W + rx + cx;                 // columns past the level's edge (width rounding) read
-            gp = gp < S ? gp : S - 1;                              // valid-but-unused pixels
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(plane + (size_t)gp * kTlGPixB + (unsigned)c * 16u),
+            const int gc = gp < S ? gp : S - 1;                   // columns past the level's edge (width rounding) read
+            __builtin_amdgcn_global_load_lds(                     // valid-but-unused pixels
+                (const __attribute__((address_space(1))) void *)(plane + ((unsigned)gc * kTlGPixB + lane16)),
                 (__attribute__((address_space(3))) void *)(lds + buf + (unsigned)(i & ~63) * 16u), 16, 0, 0);
+            cx += dc;
+            const bool w = cx >= rw;
+            cx -= w ? rw : 0;
+            gp += step + (w ? wrap : 0);
         }
     };
 
@@ -377,8 +412,9 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     // one MFMA step: 8 samples (queries 8 o' .. 8 o' + 7, point p) x 32 channels.
     // oa / ob = LDS offsets of this lane's row (corner tq) of samples 2g / 2g + 1
     auto mfma_step = [&](int op, int p, unsigned oa, unsigned ob, f32x4 &d0, f32x4 &d1) {
-        const u32x2 aw = *reinterpret_cast<const u32x2 *>(lds + w_rd + op * 512 + p * 16);
-        const u32x4 af = {aw.x & a_mlo, aw.y & a_mlo, aw.x & a_mhi, aw.y & a_mhi};
+        const u32x2 alo = *reinterpret_cast<const u32x2 *>(lds + w_rd_lo + op * 512 + p * 16);
+        const u32x2 ahi = *reinterpret_cast<const u32x2 *>(lds + w_rd_hi + op * 512 + p * 16);
+        const u32x4 af = {alo.x, alo.y, ahi.x, ahi.y};
         const unsigned ba = oa + c0, bb = ob + c0;
         const tl_s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tl_s16x4 *)(lds + ba));
         const tl_s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tl_s16x4 *)(lds + bb));
@@ -397,7 +433,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         const int ry = __builtin_amdgcn_readfirstlane(sh.desc[par][l][1]);
         const int rw = __builtin_amdgcn_readfirstlane(sh.desc[par][l][2]);
         const int rh = __builtin_amdgcn_readfirstlane(sh.desc[par][l][3]);
-        const int W = sh.w[l], H = sh.h[l];
+        const int W = LW[l], H = LH[l];
         const unsigned buf = l < 2 ? (unsigned)kTlBufAOff : (unsigned)kTlBufBOff;
         const TileCorner c = tl_corners(sm.xy[l], sm.a[l], sm.q >= 0, W, H);
         const bool in_rect = c.xa >= rx && c.xb < rx + rw && c.ya >= ry && c.yb < ry + rh;
@@ -408,19 +444,17 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
             const unsigned dx = (unsigned)(c.xb - c.xa) * kTlPixB, dy = (unsigned)(c.yb - c.ya) * (unsigned)rw * kTlPixB;
             o = u32x4{o00, o00 + dx, o00 + dy, o00 + dy + dx};
         }
-        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-        tl_split(c.w00, h0, l0);
-        tl_split(c.w01, h1, l1);
-        tl_split(c.w10, h2, l2);
-        tl_split(c.w11, h3, l3);
+        unsigned h01, h23, l01, l23;
+        tl_split2(c.w00, c.w01, h01, l01);
+        tl_split2(c.w10, c.w11, h23, l23);
         *reinterpret_cast<u32x4 *>(stage + lane * 16) = o;
-        *reinterpret_cast<u32x4 *>(stage + 1024 + lane * 16) = u32x4{h0 | (h1 << 16), h2 | (h3 << 16), l0 | (l1 << 16), l2 | (l3 << 16)};
+        *reinterpret_cast<u32x4 *>(stage + 1024 + lane * 16) = u32x4{h01, h23, l01, l23};
         unsigned long long fmask = __ballot(flagged);          // remaining flagged samples (bit = set-up lane = query * 4 + point)
 
         // flagged samples: publish the global byte offsets of four of them, start their row loads (lane = sample g,
         // corner tq, 16-byte chunk tp) -- the loads land behind the pass's DMA fill, i.e. by the time the MFMA loop is done
         u32x4 pre = {0u, 0u, 0u, 0u};
-        const unsigned g00 = (unsigned)(sh.start[l] + c.ya * W + c.xa) * kTlGPixB;
+        const unsigned g00 = (unsigned)(LS[l] + c.ya * W + c.xa) * kTlGPixB;
         const unsigned gdx = (unsigned)(c.xb - c.xa) * kTlGPixB, gdy = (unsigned)(c.yb - c.ya) * (unsigned)W * kTlGPixB;
         const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0));
         auto issue_patch_loads = [&](int first_rank) {
@@ -438,14 +472,17 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        // all eight steps' row offsets first (one LDS round trip instead of one per step), then the transposed reads and
+        // MFMAs stream behind each other
+        unsigned soa[8], sob[8];
 #pragma unroll
-        for (int op = 0; op < 2; ++op) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const unsigned *orow = reinterpret_cast<const unsigned *>(lds + o_rd + op * 512 + p * 16);
-                mfma_step(op, p, orow[0], orow[16], acc[op][0], acc[op][1]);
-            }
+        for (int st = 0; st < 8; ++st) {
+            const unsigned *orow = reinterpret_cast<const unsigned *>(lds + o_rd + (st >> 2) * 512 + (st & 3) * 16);
+            soa[st] = orow[0];
+            sob[st] = orow[16];
         }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) mfma_step(st >> 2, st & 3, soa[st], sob[st], acc[st >> 2][0], acc[st >> 2][1]);
 
         // patch steps: the rows of up to four flagged samples at a time go into the (now dead) offset area, then one MFMA
         // step per sample with every other row of the operand pointing at the zero row
@@ -507,12 +544,15 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     };
 
     // ---- pipeline ----------------------------------------------------------------------------------------------
+    if (wave == 0 && lane < 16) {
+        compute_geometry(t0, lane);
+        if (t0 + 1 < t1) compute_geometry(t0 + 1, lane);
+    }
+    __syncthreads();
     TileSamples cur, nxt;
     load_samples(t0, cur);
     nxt = cur;
-    bbox_accumulate(cur);
-    __syncthreads();
-    if (tid < kTlLevels) compute_desc(tid, t0 & 1);
+    if (tid < kTlLevels) fixed_desc(tid, t0);
     __syncthreads();
     fill(0, t0 & 1);
     __syncthreads();
@@ -526,25 +566,25 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
 #pragma unroll
             for (int X = 0; X < 2; ++X) acc[op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        fill(2, par);                                   // pass 0: level 0 from A   | level 2 -> B in flight
-        if (has_next) load_samples(t + 1, nxt);
-        if (busy) pass(0, par, cur);
+        if (!(dbg & 2)) fill(2, par);                                   // pass 0: level 0 from A   | level 2 -> B in flight
+        if (has_next && !(dbg & 16)) load_samples(t + 1, nxt);
+        if (busy && !(dbg & 4)) pass(0, par, cur);
         __syncthreads();
 
-        fill(1, par);                                   // pass 1: level 2 from B   | level 1 -> A in flight
-        if (busy) pass(2, par, cur);
-        if (has_next) bbox_accumulate(nxt);
+        if (!(dbg & 2)) fill(1, par);                                   // pass 1: level 2 from B   | level 1 -> A in flight
+        if (busy && !(dbg & 4)) pass(2, par, cur);
         __syncthreads();
 
-        fill(3, par);                                   // pass 2: level 1 from A   | level 3 -> B in flight
-        if (has_next && tid < kTlLevels) compute_desc(tid, par ^ 1);
-        if (busy) pass(1, par, cur);
+        if (!(dbg & 2)) fill(3, par);                                   // pass 2: level 1 from A   | level 3 -> B in flight
+        if (has_next && tid < kTlLevels) fixed_desc(tid, t + 1);
+        if (busy && !(dbg & 4)) pass(1, par, cur);
         __syncthreads();
 
-        if (has_next) fill(0, par ^ 1);                 // pass 3: level 3 from B   | next tile's level 0 -> A in flight
+        if (t + 2 < t1 && wave == 1 && lane < 16) compute_geometry(t + 2, lane);       // read from pass 0 of tile t + 1 on
+        if (has_next && !(dbg & 2)) fill(0, par ^ 1);                 // pass 3: level 3 from B   | next tile's level 0 -> A in flight
         if (busy) {
-            pass(3, par, cur);
-            store_tile(cur);
+            if (!(dbg & 4)) pass(3, par, cur);
+            if (!(dbg & 8)) store_tile(cur);
         }
         cur = nxt;
         __syncthreads();
@@ -558,11 +598,13 @@ int msda_tile_forward(const uint16_t *value, const int64_t *shapes, const int64_
                       hipStream_t stream)
 {
     if (L != kTlLevels || Nq != S || S < 4096) return RDETR_ERR_UNSUPPORTED;
-    if ((long long)S * kTlGPixB >= (1ll << 31)) return RDETR_ERR_UNSUPPORTED;
+    if ((long long)S * kTlGPixB >= (1ll << 31) || S > (1 << 21)) return RDETR_ERR_UNSUPPORTED;     // tile geometry: 2 * 16 * w * regions < 2^24
     auto kern = msda_fwd_tile_kernel<FUSED>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kTlLdsBytes);
     if (attr != hipSuccess) return RDETR_ERR_LAUNCH;
+    static const int dbg = []() { const char *e = getenv("RDETR_TILE_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
+    static const int rect_cfg = []() { const char *e = getenv("RDETR_TILE_RECT"); return e ? atoi(e) : 0; }();
     const long long pairs = (long long)B * kTlHeads;
     long long splits = 256 / pairs;                 // one resident workgroup per CU
     if (splits < 1) splits = 1;
@@ -570,7 +612,7 @@ int msda_tile_forward(const uint16_t *value, const int64_t *shapes, const int64_
     const long long nblk = pairs * splits;
     if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kTlThreads), (size_t)kTlLdsBytes, stream, value, shapes,
-                       level_start, src_a, src_b, ref, ref_dim, S, (int)splits, (int)nblk, out);
+                       level_start, src_a, src_b, ref, ref_dim, S, (int)splits, (int)nblk, dbg, rect_cfg, out);
     return launch_status();
 }
 

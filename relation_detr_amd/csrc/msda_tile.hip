@@ -149,6 +149,9 @@ __device__ __forceinline__ void tl_split2(float a, float b, unsigned &hi, unsign
     lo = __builtin_bit_cast(unsigned, tl_bf16x2{(__bf16)ra, (__bf16)rb});
 }
 
+// retire this wave's LDS-DMA before the barrier that publishes the buffer (the compiler does not know about it)
+__device__ __forceinline__ void tl_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <bool FUSED>
 __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     const uint16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
@@ -397,9 +400,16 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         const unsigned lane16 = (unsigned)(tid & 3) * 16u;
         for (int i = tid; i < n4; i += kTlThreads) {
             const int gc = gp < S ? gp : S - 1;                   // columns past the level's edge (width rounding) read
-            __builtin_amdgcn_global_load_lds(                     // valid-but-unused pixels
-                (const __attribute__((address_space(1))) void *)(plane + ((unsigned)gc * kTlGPixB + lane16)),
-                (__attribute__((address_space(3))) void *)(lds + buf + (unsigned)(i & ~63) * 16u), 16, 0, 0);
+            // valid-but-unused pixels.  The DMA is issued through inline assembly ON PURPOSE: hipcc tracks the builtin as
+            // an LDS write and drains it (s_waitcnt vmcnt(0)) before the pass's first LDS read, which serialises fill and
+            // gather; untracked, it stays in flight behind the MFMA loop and is retired by tl_dma_wait() before the barrier
+            // that hands the buffer over.  (M0 = LDS destination of the wave's lane 0, lanes land 16 bytes apart.)
+            const unsigned voff = (unsigned)gc * kTlGPixB + lane16;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(buf + (unsigned)(i & ~63) * 16u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :
+                         : "s"(m0v), "v"(voff), "s"(plane)
+                         : "memory", "m0");
             cx += dc;
             const bool w = cx >= rw;
             cx -= w ? rw : 0;
@@ -472,17 +482,19 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // all eight steps' row offsets first (one LDS round trip instead of one per step), then the transposed reads and
-        // MFMAs stream behind each other
-        unsigned soa[8], sob[8];
+        // four steps' row offsets at a time (one LDS round trip per octet), then the transposed reads and MFMAs stream
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            const unsigned *orow = reinterpret_cast<const unsigned *>(lds + o_rd + (st >> 2) * 512 + (st & 3) * 16);
-            soa[st] = orow[0];
-            sob[st] = orow[16];
+        for (int op = 0; op < 2; ++op) {
+            unsigned soa[4], sob[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned *orow = reinterpret_cast<const unsigned *>(lds + o_rd + op * 512 + p * 16);
+                soa[p] = orow[0];
+                sob[p] = orow[16];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) mfma_step(op, p, soa[p], sob[p], acc[op][0], acc[op][1]);
         }
-#pragma unroll
-        for (int st = 0; st < 8; ++st) mfma_step(st >> 2, st & 3, soa[st], sob[st], acc[st >> 2][0], acc[st >> 2][1]);
 
         // patch steps: the rows of up to four flagged samples at a time go into the (now dead) offset area, then one MFMA
         // step per sample with every other row of the operand pointing at the zero row
@@ -509,12 +521,15 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
             done += 4;
             if (fmask != 0ull) issue_patch_loads(done);          // more than four: next batch (its latency is exposed; rare)
         }
+        // retire the patch load for the compiler's bookkeeping at the END of the pass (otherwise it parks its wait on the
+        // first instruction of the next pass that re-uses these registers -- behind that pass's DMA)
+        asm volatile("" ::"v"(pre.x), "v"(pre.y), "v"(pre.z), "v"(pre.w));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads before the next pass's staging writes
         __builtin_amdgcn_wave_barrier();
     };
 
     // out[query][channel] = D[hi row] + D[lo row]; transposed through the wave's staging area so that a lane stores 16 bytes
-    auto store_tile = [&](const TileSamples &sm) {
+    auto store_tile = [&](int sq) {
         float *tr = reinterpret_cast<float *>(stage);
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
@@ -531,13 +546,13 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(tr + qx * 32 + pp * 8);
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(tr + qx * 32 + pp * 8 + 4);
-        if (sm.q >= 0) {
+        if (sq >= 0) {
             u32x4 w;
             w.x = f32_to_bf16_bits(lo.x) | (f32_to_bf16_bits(lo.y) << 16);
             w.y = f32_to_bf16_bits(lo.z) | (f32_to_bf16_bits(lo.w) << 16);
             w.z = f32_to_bf16_bits(hi.x) | (f32_to_bf16_bits(hi.y) << 16);
             w.w = f32_to_bf16_bits(hi.z) | (f32_to_bf16_bits(hi.w) << 16);
-            *reinterpret_cast<u32x4 *>(out + ((size_t)b * Nq + sm.q) * (kTlHeads * kTlHeadDim) + m * kTlHeadDim + pp * 8) = w;
+            *reinterpret_cast<u32x4 *>(out + ((size_t)b * Nq + sq) * (kTlHeads * kTlHeadDim) + m * kTlHeadDim + pp * 8) = w;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -549,12 +564,14 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         if (t0 + 1 < t1) compute_geometry(t0 + 1, lane);
     }
     __syncthreads();
-    TileSamples cur, nxt;
-    load_samples(t0, cur);
-    nxt = cur;
+    TileSamples cur;                       // ONE register set: the next tile's locations are loaded in pass 3, after the
+    load_samples(t0, cur);                 // last set-up of the current tile has consumed them (a second set spills)
+#pragma unroll
+    for (int l = 0; l < kTlLevels; ++l) asm volatile("" ::"v"(cur.xy[l].x), "v"(cur.xy[l].y), "v"(cur.a[l]));   // retire the loads (see pass 3)
     if (tid < kTlLevels) fixed_desc(tid, t0);
     __syncthreads();
     fill(0, t0 & 1);
+    tl_dma_wait();
     __syncthreads();
 
     for (int t = t0; t < t1; ++t) {
@@ -567,26 +584,32 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
             for (int X = 0; X < 2; ++X) acc[op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         if (!(dbg & 2)) fill(2, par);                                   // pass 0: level 0 from A   | level 2 -> B in flight
-        if (has_next && !(dbg & 16)) load_samples(t + 1, nxt);
         if (busy && !(dbg & 4)) pass(0, par, cur);
+        tl_dma_wait();
         __syncthreads();
 
         if (!(dbg & 2)) fill(1, par);                                   // pass 1: level 2 from B   | level 1 -> A in flight
         if (busy && !(dbg & 4)) pass(2, par, cur);
+        tl_dma_wait();
         __syncthreads();
 
         if (!(dbg & 2)) fill(3, par);                                   // pass 2: level 1 from A   | level 3 -> B in flight
         if (has_next && tid < kTlLevels) fixed_desc(tid, t + 1);
         if (busy && !(dbg & 4)) pass(1, par, cur);
+        tl_dma_wait();
         __syncthreads();
 
         if (t + 2 < t1 && wave == 1 && lane < 16) compute_geometry(t + 2, lane);       // read from pass 0 of tile t + 1 on
         if (has_next && !(dbg & 2)) fill(0, par ^ 1);                 // pass 3: level 3 from B   | next tile's level 0 -> A in flight
-        if (busy) {
-            if (!(dbg & 4)) pass(3, par, cur);
-            if (!(dbg & 8)) store_tile(cur);
-        }
-        cur = nxt;
+        if (busy && !(dbg & 4)) pass(3, par, cur);
+        const int sq = cur.q;
+        if (has_next && !(dbg & 16)) load_samples(t + 1, cur);
+        if (busy && !(dbg & 8)) store_tile(sq);
+        // make the compiler retire the location loads HERE (it waits lazily, at the first use -- which would be inside the
+        // next pass, behind that pass's untracked DMA, and would drain it)
+#pragma unroll
+        for (int l = 0; l < kTlLevels; ++l) asm volatile("" ::"v"(cur.xy[l].x), "v"(cur.xy[l].y), "v"(cur.a[l]));
+        tl_dma_wait();
         __syncthreads();
     }
 }

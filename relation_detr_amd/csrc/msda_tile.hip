@@ -332,13 +332,14 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
                 }
             }
         } else {
-            const float *loc_q = static_cast<const float *>(src_a) + hrow * 2;
-            const float *att_q = static_cast<const float *>(src_b) + hrow;
+            // 32-bit element offsets from the image's (uniform) base: B * Nq * 8 * 16 * 2 floats can exceed 2^32, one image cannot
+            const float *loc_b = static_cast<const float *>(src_a) + (size_t)b * Nq * (kTlHeads * kTlLevels * kTlPoints * 2);
+            const float *att_b = static_cast<const float *>(src_b) + (size_t)b * Nq * (kTlHeads * kTlLevels * kTlPoints);
+            const unsigned e = ((unsigned)(sm.q >= 0 ? sm.q : 0) * kTlHeads + (unsigned)m) * (kTlLevels * kTlPoints) + (unsigned)pp;
 #pragma unroll
             for (int l = 0; l < kTlLevels; ++l) {
-                const int pt = l * kTlPoints + pp;
-                sm.xy[l] = *reinterpret_cast<const f32x2 *>(loc_q + 2 * pt);
-                sm.a[l] = att_q[pt];
+                sm.xy[l] = *reinterpret_cast<const f32x2 *>(loc_b + 2u * (e + (unsigned)(l * kTlPoints)));
+                sm.a[l] = att_b[e + (unsigned)(l * kTlPoints)];
             }
         }
     };
@@ -464,12 +465,14 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         // flagged samples: publish the global byte offsets of four of them, start their row loads (lane = sample g,
         // corner tq, 16-byte chunk tp) -- the loads land behind the pass's DMA fill, i.e. by the time the MFMA loop is done
         u32x4 pre = {0u, 0u, 0u, 0u};
-        const unsigned g00 = (unsigned)(LS[l] + c.ya * W + c.xa) * kTlGPixB;
-        const unsigned gdx = (unsigned)(c.xb - c.xa) * kTlGPixB, gdy = (unsigned)(c.yb - c.ya) * (unsigned)W * kTlGPixB;
-        const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0));
+        const unsigned long long fmask0 = fmask;
         auto issue_patch_loads = [&](int first_rank) {
-            if (flagged && frank >= first_rank && frank < first_rank + 4)
+            const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask0, 0));
+            if (flagged && frank >= first_rank && frank < first_rank + 4) {
+                const unsigned g00 = (unsigned)(LS[l] + c.ya * W + c.xa) * kTlGPixB;
+                const unsigned gdx = (unsigned)(c.xb - c.xa) * kTlGPixB, gdy = (unsigned)(c.yb - c.ya) * (unsigned)W * kTlGPixB;
                 *reinterpret_cast<u32x4 *>(fgo + (frank - first_rank) * 16) = u32x4{g00, g00 + gdx, g00 + gdy, g00 + gdy + gdx};
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

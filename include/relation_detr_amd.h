@@ -216,6 +216,19 @@ int rdetr_add_layernorm_strided_bf16(const uint16_t *x, const uint16_t *residual
                                      const uint16_t *beta, long long rows, int C, long long ldx, long long ldr,
                                      long long ldo, float eps, uint16_t *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused elementwise steps of the decoder's box bookkeeping (each replaces ~8 torch launches on a [B,N,4] tensor).
+ *   rdetr_box_refine_f32   out = sigmoid(delta + inverse_sigmoid(ref)),  inverse_sigmoid as util/misc.py:31-35 (eps 1e-3);
+ *                          the iterative box refinement of models/bricks/relation_transformer.py:363-381.
+ *                          delta: n values, fp32 (delta_is_bf16 = 0) or bf16 (1); ref, out: n fp32 values.
+ *   rdetr_sine_pos_embed   get_sine_pos_embed(pos, num_pos_feats = F, temperature, scale, exchange_xy = True)
+ *                          (models/bricks/position_encoding.py:101-138): pos fp32 [rows, n] -> out [rows, n * F] fp32 or bf16,
+ *                          coordinate order (y, x, rest), channel = coord * F + 2k + {sin, cos}, F even, <= 128. */
+int rdetr_box_refine_f32(const void *delta, int delta_is_bf16, const float *ref, long long n, float eps, float *out,
+                         void *stream);
+int rdetr_sine_pos_embed(const float *pos, long long rows, int n, int F, float temperature, float scale, void *out,
+                         int out_is_bf16, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -401,3 +401,31 @@ def relation_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_he
         float(scale if scale is not None else D ** -0.5), out.data_ptr(), C, _stream_ptr(q))
     _lib.check(st, "rdetr_relation_attention_bf16")
     return out
+
+
+def box_refine(delta: torch.Tensor, reference: torch.Tensor, eps: float = 1e-3) -> torch.Tensor:
+    """sigmoid(delta + inverse_sigmoid(reference)) in one kernel; delta fp32 / bf16, reference fp32 -> fp32."""
+    _require_device(delta, reference)
+    if delta.shape != reference.shape or reference.dtype != torch.float32 or delta.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.RdetrError("box_refine: delta (fp32 / bf16) and reference (fp32) must have the same shape")
+    delta, reference = delta.contiguous(), reference.contiguous()
+    out = torch.empty_like(reference)
+    st = _lib.load().rdetr_box_refine_f32(delta.data_ptr(), int(delta.dtype == torch.bfloat16), reference.data_ptr(),
+                                          reference.numel(), float(eps), out.data_ptr(), _stream_ptr(reference))
+    _lib.check(st, "rdetr_box_refine_f32")
+    return out
+
+
+def sine_pos_embed(pos: torch.Tensor, num_pos_feats: int = 128, temperature: float = 10000.0, scale: float = 6.283185307179586,
+                   dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """get_sine_pos_embed(..., exchange_xy=True) in one kernel: pos fp32 [..., n] -> [..., n * num_pos_feats] (fp32 / bf16)."""
+    _require_device(pos)
+    if pos.dtype != torch.float32 or dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.RdetrError("sine_pos_embed: pos must be float32, output float32 or bfloat16")
+    pos = pos.contiguous()
+    n = pos.shape[-1]
+    out = torch.empty(*pos.shape[:-1], n * num_pos_feats, dtype=dtype, device=pos.device)
+    st = _lib.load().rdetr_sine_pos_embed(pos.data_ptr(), pos.numel() // n, n, num_pos_feats, float(temperature), float(scale),
+                                          out.data_ptr(), int(dtype == torch.bfloat16), _stream_ptr(pos))
+    _lib.check(st, "rdetr_sine_pos_embed")
+    return out

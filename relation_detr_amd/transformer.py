@@ -34,6 +34,15 @@ def inverse_sigmoid(x: Tensor, eps: float = 1e-3) -> Tensor:
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
+def refine_boxes(delta: Tensor, reference: Tensor) -> Tensor:
+    """sigmoid(delta + inverse_sigmoid(reference)) -- the iterative box refinement (relation_transformer.py:363-381); boxes stay
+    fp32 whatever the network dtype.  One HIP kernel on a device without autograd, torch otherwise."""
+    if delta.is_cuda and reference.dtype == torch.float32 and not (torch.is_grad_enabled() and delta.requires_grad):
+        from . import ops
+        return ops.box_refine(delta, reference)
+    return (delta.float() + inverse_sigmoid(reference)).sigmoid()
+
+
 def sine_pos_embed(pos: Tensor, num_pos_feats: int = 128, temperature: float = 10000.0,
                    scale: float = 2 * math.pi) -> Tensor:
     """get_sine_pos_embed with exchange_xy=True (models/bricks/position_encoding.py:115-138):
@@ -202,7 +211,12 @@ class RelationTransformerDecoder(nn.Module):
         tgt_boxes = None
         for idx, layer in enumerate(self.layers):
             ref_in = reference_points.detach()[:, :, None] * ratio_scale            # [B,N,L,4]
-            query_pos = self.ref_point_head(sine_pos_embed(ref_in[:, :, 0, :], self.embed_dim // 2).to(query.dtype))
+            if ref_in.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16):
+                from . import ops
+                emb = ops.sine_pos_embed(ref_in[:, :, 0, :].float(), self.embed_dim // 2, dtype=query.dtype)
+            else:
+                emb = sine_pos_embed(ref_in[:, :, 0, :], self.embed_dim // 2).to(query.dtype)
+            query_pos = self.ref_point_head(emb)
             if idx != 0:
                 query_pos = query_pos * self.query_scale(query)
             query = layer(query=query, query_pos=query_pos, reference_points=ref_in, value=value,
@@ -211,7 +225,7 @@ class RelationTransformerDecoder(nn.Module):
             normed = add_norm(self.norm, query)
             out_class = self.class_head[idx](normed)
             # boxes stay fp32 whatever the network dtype (a bf16 + fp32 add takes torch's slow mixed-dtype kernel)
-            out_coord = (self.bbox_head[idx](normed).float() + inverse_sigmoid(reference_points)).sigmoid()
+            out_coord = refine_boxes(self.bbox_head[idx](normed), reference_points)
             classes.append(out_class)
             coords.append(out_coord)
             if idx == self.num_layers - 1:
@@ -222,7 +236,7 @@ class RelationTransformerDecoder(nn.Module):
                 pos_relation = self.position_relation_embedding(src_boxes, tgt_boxes).flatten(0, 1)
                 if attn_mask is not None:
                     pos_relation.masked_fill_(attn_mask, float("-inf"))
-            reference_points = (self.bbox_head[idx](query).float() + inverse_sigmoid(reference_points.detach())).sigmoid()
+            reference_points = refine_boxes(self.bbox_head[idx](query), reference_points.detach())
         return torch.stack(classes), torch.stack(coords)
 
 
@@ -333,7 +347,7 @@ class RelationTransformer(nn.Module):
 
         out_memory, out_proposals = self.encoder_output(memory, proposals, mask)
         enc_class = self.encoder_class_head(out_memory)
-        enc_coord = (self.encoder_bbox_head(out_memory) + out_proposals).sigmoid()
+        enc_coord = (self.encoder_bbox_head(out_memory).float() + out_proposals).sigmoid()      # fp32 boxes, no mixed-dtype add
         k = self.two_stage_num_proposals
         top = torch.topk(enc_class.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
         enc_class = enc_class.gather(1, top.expand(-1, -1, self.num_classes))

@@ -183,3 +183,30 @@ def test_add_layer_norm_column_slices(dtype):
     tol = 2e-5 if dtype == torch.float32 else 2.0 ** -7
     assert (o.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
     assert out_wide[..., :1024].abs().max().item() == 0 and out_wide[..., 1280:].abs().max().item() == 0   # nothing else touched
+
+
+# ------------------------------------------------------------------------------------------ decoder box bookkeeping
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_box_refine_vs_torch(dtype):
+    from relation_detr_amd import ops
+    from relation_detr_amd.transformer import inverse_sigmoid
+    g = torch.Generator().manual_seed(9)
+    ref = torch.rand(4, 900, 4, generator=g)
+    ref[0, 0] = torch.tensor([0.0, 1.0, 1e-5, 0.9995])          # the clamps of inverse_sigmoid (util/misc.py:31-35)
+    delta = (torch.randn(4, 900, 4, generator=g) * 2).to(dtype)
+    out = ops.box_refine(delta.to(DEV), ref.to(DEV)).cpu()
+    expect = (delta.float() + inverse_sigmoid(ref)).sigmoid()
+    np.testing.assert_allclose(out.numpy(), expect.numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("n,F,dtype", [(4, 128, torch.float32), (2, 128, torch.float32), (4, 128, torch.bfloat16), (4, 16, torch.float32)])
+def test_sine_pos_embed_vs_torch(n, F, dtype):
+    from relation_detr_amd import ops
+    from relation_detr_amd.transformer import sine_pos_embed
+    g = torch.Generator().manual_seed(n + F)
+    pos = torch.rand(3, 77, n, generator=g)
+    out = ops.sine_pos_embed(pos.to(DEV), F, dtype=dtype).float().cpu()
+    expect = sine_pos_embed(pos, F)
+    assert out.shape == expect.shape == (3, 77, n * F)
+    tol = 5e-6 if dtype == torch.float32 else 2.0 ** -8
+    np.testing.assert_allclose(out.numpy(), expect.numpy(), rtol=0, atol=tol)

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // four steps' row offsets at a time (one LDS round trip per octet), then the transposed reads and MFMAs stream
+        if (!(dbg & 32))
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
             unsigned soa[4], sob[4];

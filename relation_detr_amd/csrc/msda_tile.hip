@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     };
 
     // one level of the wave's 16 queries: set-up (lane = query x point) -> staging -> MFMA loop -> patch steps for flagged samples
-    auto pass = [&](int l, int par, const TileSamples &sm) {
+    auto pass = [&](int l, int par, const TileSamples &sm, auto &&after_setup) {
         const int rx = __builtin_amdgcn_readfirstlane(sh.desc[par][l][0]);
         const int ry = __builtin_amdgcn_readfirstlane(sh.desc[par][l][1]);
         const int rw = __builtin_amdgcn_readfirstlane(sh.desc[par][l][2]);
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // staging is private to the wave: wave-level ordering suffices
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        after_setup();                       // the locations are consumed: pass 3 starts loading the next tile's here
 
         // four steps' row offsets at a time (one LDS round trip per octet), then the transposed reads and MFMAs stream
         if (!(dbg & 32))
@@ -588,26 +589,32 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
             for (int X = 0; X < 2; ++X) acc[op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         if (!(dbg & 2)) fill(2, par);                                   // pass 0: level 0 from A   | level 2 -> B in flight
-        if (busy && !(dbg & 4)) pass(0, par, cur);
+        if (busy && !(dbg & 4)) pass(0, par, cur, [] {});
         tl_dma_wait();
         __syncthreads();
 
         if (!(dbg & 2)) fill(1, par);                                   // pass 1: level 2 from B   | level 1 -> A in flight
-        if (busy && !(dbg & 4)) pass(2, par, cur);
+        if (busy && !(dbg & 4)) pass(2, par, cur, [] {});
         tl_dma_wait();
         __syncthreads();
 
         if (!(dbg & 2)) fill(3, par);                                   // pass 2: level 1 from A   | level 3 -> B in flight
         if (has_next && tid < kTlLevels) fixed_desc(tid, t + 1);
-        if (busy && !(dbg & 4)) pass(1, par, cur);
+        if (busy && !(dbg & 4)) pass(1, par, cur, [] {});
         tl_dma_wait();
         __syncthreads();
 
         if (t + 2 < t1 && wave == 1 && lane < 16) compute_geometry(t + 2, lane);       // read from pass 0 of tile t + 1 on
         if (has_next && !(dbg & 2)) fill(0, par ^ 1);                 // pass 3: level 3 from B   | next tile's level 0 -> A in flight
-        if (busy && !(dbg & 4)) pass(3, par, cur);
         const int sq = cur.q;
-        if (has_next && !(dbg & 16)) load_samples(t + 1, cur);
+        bool loaded = false;
+        if (busy && !(dbg & 4)) {
+            pass(3, par, cur, [&] {            // after the last set-up of the tile the locations are dead: fetch the next tile's
+                if (has_next && !(dbg & 16)) load_samples(t + 1, cur);     // behind the MFMA loop and the store
+            });
+            loaded = true;
+        }
+        if (!loaded && has_next && !(dbg & 16)) load_samples(t + 1, cur);
         if (busy && !(dbg & 8)) store_tile(sq);
         // make the compiler retire the location loads HERE (it waits lazily, at the first use -- which would be inside the
         // next pass, behind that pass's untracked DMA, and would drain it)

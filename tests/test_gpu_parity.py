@@ -437,3 +437,34 @@ def test_encoder_entry_fused_matches_unfused(rd, dtype, monkeypatch):
     else:
         err = (out.float().cpu() - expect).abs()
         assert (err <= 2.0 ** -8 * expect.abs() + 1e-3).all(), err.max()
+
+
+# ------------------------------------------------------------------------------------------ FocalNet-size pyramid
+FOCAL = [(304, 504), (152, 252), (76, 126), (38, 63), (19, 32)]      # BASELINE.json configs[4]: 1216 x 2016 padded, 5 levels
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_focalnet_size_pyramid(rd, dtype):
+    """S = 204,098 positions, L = 5 (relation_detr_focalnet_large_lrf_fl4_1200_2000): a 5,000-query launch against the C
+    oracle, and the full encoder-shape launch (Nq = S) must reproduce those rows bit for bit (same kernel, same inputs per
+    row) and stay finite everywhere."""
+    from oracle import c_oracle
+    shp, start, S = pyramid(FOCAL)
+    assert S == 204098
+    g = torch.Generator().manual_seed(77)
+    value = torch.randn(1, S, 8, 32, generator=g).to(dtype)
+    loc = (torch.rand(1, S, 8, 5, 4, 2, generator=g) * 1.1 - 0.05)
+    attn = torch.softmax(torch.randn(1, S, 8, 20, generator=g), -1).view(1, S, 8, 5, 4)
+    pick = torch.randperm(S, generator=g)[:5000].sort().values
+    v_d, shp_d, start_d = value.to(DEV), shp.to(DEV), start.to(DEV)
+    sub = rd.ms_deform_attn_forward(v_d, shp_d, start_d, loc[:, pick].contiguous().to(DEV), attn[:, pick].contiguous().to(DEV), 64)
+    ref = c_oracle.msda_forward(value.float().numpy(), shp.numpy(), start.numpy(), loc[:, pick].contiguous().numpy(),
+                                attn[:, pick].contiguous().numpy())
+    got = sub.float().cpu().numpy()
+    if dtype == torch.float32:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4)
+    else:
+        assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-3).all()
+    full = rd.ms_deform_attn_forward(v_d, shp_d, start_d, loc.to(DEV), attn.to(DEV), 64)
+    assert torch.isfinite(full.float()).all()
+    assert torch.equal(full[:, pick.to(DEV)], sub)

@@ -250,6 +250,36 @@ def main():
     t_kernel, S, L = time_encoder_kernel(B, dev, dtype)
     alg = msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2 if args.dtype == "bf16" else 4)
 
+    # BASELINE.json quotes the metric "@ 300 queries" while the reference config of that name runs 900 two-stage queries and
+    # keeps 300 detections (what `value` measures).  For the record, the same stack with 300 two-stage queries as well
+    # (N = 1, rank 0, its own short timed loop; not `value`).
+    alt_300 = None
+    if world == 1 and rank == 0 and Nq != 300 and os.environ.get("RDETR_BENCH_ALT300", "1") != "0":
+        try:
+            net300 = build_network(300, 0).to(dev).to(dtype)
+
+            @torch.no_grad()
+            def forward300(*t):
+                classes, coords, _, _ = net300(list(t[:L0]), list(t[L0:2 * L0]), list(t[2 * L0:3 * L0]))
+                return select_detections(classes[-1].float(), coords[-1].float(), t[3 * L0])
+
+            L0 = len(feats)
+            run300 = forward300
+            if launch == "hipGraph replay":
+                from relation_detr_amd.graph import GraphedCall
+                run300 = GraphedCall(forward300, flat_inputs)
+            for _ in range(3):
+                run300(*flat_inputs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                run300(*flat_inputs)
+            torch.cuda.synchronize()
+            alt_300 = B * 10 / (time.perf_counter() - t1)
+            del net300, run300
+        except RuntimeError as e:
+            print(f"[bench] 300-query variant skipped ({type(e).__name__}: {str(e)[:160]})", file=sys.stderr)
+
     if rank == 0:
         res = {
             "metric": "images/sec @ 800x1333, R50 4-level; achieved HBM GB/s",
@@ -260,7 +290,7 @@ def main():
                                    "layers (MSDA self-attn, S=22323) + two-stage top-k + 6 decoder layers (relation-biased "
                                    "self-attn + MSDA cross-attn + box refinement) + top-300 detections; backbone/neck excluded",
                        "batch_per_gpu": B, "global_batch": B * world, "queries": Nq, "levels": 4,
-                       "launch": launch, "gemm_tuning": os.environ.get("PYTORCH_TUNABLEOP_ENABLED", "0") == "1",
+                       "images_per_s_with_300_two_stage_queries": alt_300, "launch": launch, "gemm_tuning": os.environ.get("PYTORCH_TUNABLEOP_ENABLED", "0") == "1",
                        "parallelism": f"image-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_qrun_kernel (encoder shape, B=%d)" % B,
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

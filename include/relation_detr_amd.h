@@ -82,6 +82,20 @@ int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_
                                   const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B, int S,
                                   int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
 
+/* Fused-producer form with `key_padding_mask` (u8 [B, S], non-zero = padded position, may be NULL) applied inside the
+ * gather: a padded pixel's row counts as zero, which is what zero-filling the projected value does
+ * (models/bricks/ms_deform_attn.py:316-319) -- without a pass over the [B, S, H*D] tensor.  Fast-path shapes only. */
+int rdetr_msda_forward_fused_masked_f32(const float *value, const int64_t *spatial_shapes,
+                                        const int64_t *level_start_index, const float *sampling_offsets,
+                                        const float *attn_logits, const float *reference_points, int ref_dim,
+                                        const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
+                                        float *out, void *stream);
+int rdetr_msda_forward_fused_masked_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                         const uint16_t *attn_logits, const float *reference_points, int ref_dim,
+                                         const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
+                                         uint16_t *out, void *stream);
+
 /* "Planned" forms of the four entry points above (H = 8, D = 32, P = 4 implied; L <= 8): identical
  * arithmetic and results, plus `host_spatial_shapes`, a HOST copy of the [L,2] (h,w) table, so that the launch can
  * be planned around the pyramid geometry (levels packed contiguously, level_start = running sum).  The reference

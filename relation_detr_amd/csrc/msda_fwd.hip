@@ -119,7 +119,8 @@ template <typename T, int LT, bool FUSED>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
-    int L_rt, int Nq, int tiles_per_image, int nblk, int tile2d, T *__restrict__ out)
+    int L_rt, int Nq, int tiles_per_image, int nblk, int tile2d, T *__restrict__ out,
+    const unsigned char *__restrict__ pad_mask)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
@@ -250,6 +251,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             o.y = (okx1 && oky0) ? base + IO::kPixelBytes : kInvalidOffset;
             o.z = (okx0 && oky1) ? base + rowb : kInvalidOffset;
             o.w = (okx1 && oky1) ? base + rowb + IO::kPixelBytes : kInvalidOffset;
+            if (pad_mask) {                  // key_padding_mask: a padded pixel's projected value row counts as zero
+                const unsigned char *mp = pad_mask + (size_t)b * S + (lvl.start[l] + y0 * w + x0);     // (ms_deform_attn.py:316-319)
+                if (okx0 && oky0 && mp[0]) o.x = kInvalidOffset;
+                if (okx1 && oky0 && mp[1]) o.y = kInvalidOffset;
+                if (okx0 && oky1 && mp[w]) o.z = kInvalidOffset;
+                if (okx1 && oky1 && mp[w + 1]) o.w = kInvalidOffset;
+            }
             f32x4 wt;
             wt.x = inside ? hy * hx * a : 0.f;
             wt.y = inside ? hy * lx * a : 0.f;
@@ -367,17 +375,17 @@ static char msda_algo()
 template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
-                        int S, int L, int Nq, int tiles, int nblk, int tile2d, T *out)
+                        int S, int L, int Nq, int tiles, int nblk, int tile2d, T *out, const unsigned char *pad_mask)
 {
     if (L == 4)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask);
     else if (L == 5)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask);
     else
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
@@ -385,7 +393,8 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
 template <typename T, bool FUSED>
 static int msda_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
                         const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
-                        int P, T *out, hipStream_t stream, const int64_t *host_shapes = nullptr, bool force_direct = false)
+                        int P, T *out, hipStream_t stream, const int64_t *host_shapes = nullptr, bool force_direct = false,
+                        const unsigned char *pad_mask = nullptr)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
     if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
@@ -398,7 +407,7 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *le
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
         if constexpr (sizeof(T) == 2) {
-            if (msda_algo() == 'l' && !host_shapes && !force_direct) {
+            if (msda_algo() == 'l' && !host_shapes && !force_direct && !pad_mask) {
                 const int st = msda_tile_forward<FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, L, Nq,
                                                         out, stream);
                 if (st != RDETR_ERR_UNSUPPORTED) return st;
@@ -422,10 +431,10 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *le
         const long long nblk = (long long)B * H * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
         launch_qrun<T, FUSED>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
-                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, tile2d, out);
+                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, tile2d, out, pad_mask);
         return launch_status();
     }
-    if (FUSED) return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
+    if (FUSED || pad_mask) return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
     const long long total = (long long)B * Nq * H * D;
     const long long want = (total + 255) / 256;
     dim3 grid((unsigned)(want < 16384 ? want : 16384)), block(256);
@@ -611,4 +620,28 @@ extern "C" int rdetr_msda_forward_fused_direct_bf16(const uint16_t *value, const
     return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
                                                reference_points, ref_dim, B, S, rdetr::kHeads, rdetr::kHeadDim, L, Nq,
                                                rdetr::kPoints, out, static_cast<hipStream_t>(stream), nullptr, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused-producer form with the padding mask applied inside the gather (no fill pass over the projected value).
+extern "C" int rdetr_msda_forward_fused_masked_f32(const float *value, const int64_t *spatial_shapes,
+                                                   const int64_t *level_start_index, const float *sampling_offsets,
+                                                   const float *attn_logits, const float *reference_points, int ref_dim,
+                                                   const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq,
+                                                   int P, float *out, void *stream)
+{
+    return rdetr::msda_forward<float, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                            reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                            static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask);
+}
+
+extern "C" int rdetr_msda_forward_fused_masked_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                                    const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                                    const uint16_t *attn_logits, const float *reference_points, int ref_dim,
+                                                    const uint8_t *key_padding_mask, int B, int S, int H, int D, int L,
+                                                    int Nq, int P, uint16_t *out, void *stream)
+{
+    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                               reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                               static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask);
 }

@@ -73,13 +73,14 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.zeros_(self.output_proj.bias)
 
-    def _projections(self, query: Tensor, value: Tensor, key_padding_mask):
-        """value projection (+ padding zero-fill, ms_deform_attn.py:316-321) and the two raw query projections."""
+    def _projections(self, query: Tensor, value: Tensor, key_padding_mask, fill: bool = True):
+        """value projection (+ padding zero-fill, ms_deform_attn.py:316-321, unless the caller applies the mask itself)
+        and the two raw query projections."""
         B, Nq, _ = query.shape
         S = value.shape[1]
         H, L, P = self.num_heads, self.num_levels, self.num_points
         v = self.value_proj(value)
-        if key_padding_mask is not None:
+        if key_padding_mask is not None and fill:
             if torch.is_grad_enabled() and v.requires_grad:
                 v = v.masked_fill(key_padding_mask[..., None], float(0))
             else:                                      # inference: fill the fresh projection in place (no clone pass)
@@ -107,13 +108,20 @@ class MultiScaleDeformableAttention(nn.Module):
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError(
                 "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
-        v, offsets, logits = self._projections(query, value, key_padding_mask)
+        fused = (value.is_cuda and not torch.is_grad_enabled()
+                 and ops.msda_fast_path(self.num_heads, self.embed_dim // self.num_heads, self.num_levels, self.num_points))
+        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not fused)
         core_dtype = v.dtype if v.dtype in (torch.float32, torch.bfloat16) else torch.float32
         needs_grad = torch.is_grad_enabled() and any(
             t.requires_grad for t in (v, offsets, logits, reference_points))
-        if (v.is_cuda and not needs_grad
+        if fused:
+            # inference: softmax + location arithmetic happen inside the gather kernel's set-up phase, and so does the
+            # padding mask (rows of padded positions count as zero: no fill pass over the projected value)
+            core = ops.ms_deform_attn_forward_fused(
+                v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype).contiguous(),
+                logits.to(core_dtype).contiguous(), reference_points.float().contiguous(), key_padding_mask)
+        elif (v.is_cuda and not needs_grad
                 and ops.msda_fast_path(self.num_heads, self.embed_dim // self.num_heads, self.num_levels, self.num_points)):
-            # inference: softmax + location arithmetic happen inside the gather kernel's set-up phase
             core = ops.ms_deform_attn_forward_fused(
                 v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype).contiguous(),
                 logits.to(core_dtype).contiguous(), reference_points.float().contiguous())

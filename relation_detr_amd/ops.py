@@ -133,7 +133,7 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
 
 def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
                                  sampling_offsets: torch.Tensor, attn_logits: torch.Tensor,
-                                 reference_points: torch.Tensor) -> torch.Tensor:
+                                 reference_points: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """MSDA with the location / weight producer fused into the gather kernel (inference path).
     value [B,S,H,D] fp32|bf16; sampling_offsets [B,Nq,H,L,P,2] and attn_logits [B,Nq,H,L*P] RAW projection
     outputs in value's dtype; reference_points [B,Nq,L,2|4] fp32 -> [B,Nq,H*D] in value's dtype.
@@ -163,6 +163,19 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
     else:
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if key_padding_mask is not None:
+        # `value` is the UNFILLED projection: the kernel treats the rows of padded positions as zero (bool [B, S], True = padded)
+        _require_device(key_padding_mask)
+        if tuple(key_padding_mask.shape) != (B, S):
+            raise _lib.RdetrError("key_padding_mask must be [B, S]")
+        mask_u8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool \
+            else key_padding_mask.to(torch.uint8).contiguous()
+        fm = lib.rdetr_msda_forward_fused_masked_f32 if value.dtype == torch.float32 else lib.rdetr_msda_forward_fused_masked_bf16
+        st = fm(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
+                attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, mask_u8.data_ptr(), B, S, H, D, L, Nq, P,
+                out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_fused_masked")
+        return out
     host = _host_shape_table(spatial_shapes, level_start_index, S, H, D, L, P)
     if host is not None:            # launch planned around the pyramid geometry (hybrid LDS / direct kernel)
         planned = (lib.rdetr_msda_forward_fused_planned_f32 if value.dtype == torch.float32

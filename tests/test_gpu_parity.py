@@ -468,3 +468,27 @@ def test_focalnet_size_pyramid(rd, dtype):
     full = rd.ms_deform_attn_forward(v_d, shp_d, start_d, loc.to(DEV), attn.to(DEV), 64)
     assert torch.isfinite(full.float()).all()
     assert torch.equal(full[:, pick.to(DEV)], sub)
+
+
+@pytest.mark.parametrize("dtype,ref_dim", [(torch.float32, 2), (torch.bfloat16, 2), (torch.float32, 4)])
+def test_msda_fused_padding_mask_inside_kernel(rd, dtype, ref_dim):
+    """key_padding_mask applied in the gather (padded rows count as zero) == zero-filling the projected value first
+    (ms_deform_attn.py:316-319): bit-identical, since a zero row and a skipped row add the same 0."""
+    shapes_l = [(23, 37), (12, 19), (6, 10), (3, 5)]
+    shp, start, S = pyramid(shapes_l)
+    g = torch.Generator().manual_seed(31 + ref_dim)
+    B, Nq, L = 2, 200, 4
+    value = torch.randn(B, S, 8, 32, generator=g).to(dtype)
+    off = (torch.randn(B, Nq, 8, L, 4, 2, generator=g) * 3).to(dtype)
+    logits = (torch.randn(B, Nq, 8, L * 4, generator=g) * 2).to(dtype)
+    ref = torch.rand(B, Nq, L, 2, generator=g)
+    if ref_dim == 4:
+        ref = torch.cat([ref, torch.rand(B, Nq, L, 2, generator=g) * 0.5 + 0.02], -1)
+    mask = torch.rand(B, S, generator=g) < 0.3                       # 30 % of the positions padded
+    dev = lambda t: t.to(DEV).contiguous()
+    got = rd.ms_deform_attn_forward_fused(dev(value), dev(shp), dev(start), dev(off), dev(logits), dev(ref), dev(mask))
+    filled = value.masked_fill(mask[:, :, None, None], 0)
+    want = rd.ms_deform_attn_forward_fused(dev(filled), dev(shp), dev(start), dev(off), dev(logits), dev(ref))
+    assert torch.equal(got, want)
+    none = rd.ms_deform_attn_forward_fused(dev(value), dev(shp), dev(start), dev(off), dev(logits), dev(ref))
+    assert not torch.equal(got, none)

@@ -180,6 +180,15 @@ int rdetr_relation_bias_f32(const float *src, const float *tgt, const float *pro
                             int B, int N1, int N2, int Hh, int F, float scale, float temperature, float eps,
                             float *out, void *stream);
 
+/* Same operator with a caller-provided workspace of (B*N1 + B*N2) * 2*F floats (8-byte aligned): for F = 16, Hh = 8 the
+ * two size-ratio coordinates log(w_i/w_j), log(h_i/h_j) take their sine features from per-box tables (angle computed in
+ * double precision once per box) by the angle-difference identities instead of evaluating sin / cos per pair -- a third
+ * fewer instructions.  Results stay within 1e-4 of both the fp32 and the fp64 evaluation of the reference formula (the
+ * fp32 reference itself rounds these angles to ~3e-5 rad).  Any other configuration forwards to rdetr_relation_bias_f32. */
+int rdetr_relation_bias_ws_f32(const float *src, const float *tgt, const float *proj_weight, const float *proj_bias,
+                               int B, int N1, int N2, int Hh, int F, float scale, float temperature, float eps,
+                               float *workspace, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bias-add + row softmax of decoder self-attention scores, in place.
  * Replaces the softmax(QK^T/sqrt(d) + attn_mask) step of nn.MultiheadAttention as called at

@@ -35,6 +35,7 @@ SIGNATURES = {
     "rdetr_msda_forward_fused_direct_bf16": [_vp] * 6 + [_c_int] * 5 + [_vp, _vp],
     "rdetr_msda_backward_f32": [_vp] * 6 + [_c_int] * 7 + [_vp] * 4,
     "rdetr_relation_bias_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp],
+    "rdetr_relation_bias_ws_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp, _vp],
     "rdetr_bias_softmax_f32": [_vp] * 3 + [_c_int] * 3 + [_vp],
     "rdetr_relation_attention_bf16": [_vp] * 3 + [_c_int] * 3 + [_vp, _vp] + [_c_int] * 5 + [_c_float, _vp, _c_int, _vp],
     "rdetr_box_refine_f32": [_vp, _c_int, _vp, _c_ll, _c_float, _vp, _vp],

@@ -63,10 +63,14 @@ constexpr int kRelRows = 4;        // query rows per lane
 constexpr int kRelWaves = 4;
 
 // Fast path: F = 16 (8 frequencies), HH = 8 heads.
-template <int F, int HH>
+// TABLES = true: the two size-ratio coordinates  log(w_i / w_j), log(h_i / h_j)  are differences of per-box terms, so their
+// sine features come from per-box tables (relation_tables_kernel) by the angle-difference identities -- 4 multiply-adds
+// instead of a division, an argument reduction and two polynomials per (pair, frequency, coordinate).
+template <int F, int HH, bool TABLES>
 __global__ __launch_bounds__(kRelWaves *kWave) void relation_bias_kernel(
     const float *__restrict__ src, const float *__restrict__ tgt, const float *__restrict__ Wp,
-    const float *__restrict__ bp, int N1, int N2, float scale, float eps, DimT dim_t, float *__restrict__ out)
+    const float *__restrict__ bp, int N1, int N2, float scale, float eps, DimT dim_t, float *__restrict__ out,
+    const float *__restrict__ src_tab, const float *__restrict__ tgt_tab)
 {
     constexpr int K = F / 2, CH = 4 * F;
     __shared__ f32x4 wT[CH * HH / 4];                      // [ch][h] transposed weights
@@ -98,22 +102,36 @@ __global__ __launch_bounds__(kRelWaves *kWave) void relation_bias_kernel(
         const float sx = sb[0], sy = sb[1], sw = sb[2] + eps, sh = sb[3] + eps;
         es[r][0] = logf(__builtin_fabsf(sx - t.x) / sw + 1.0f) * scale;
         es[r][1] = logf(__builtin_fabsf(sy - t.y) / sh + 1.0f) * scale;
-        es[r][2] = logf(sw / tw) * scale;
-        es[r][3] = logf(sh / th) * scale;
+        es[r][2] = TABLES ? 0.f : logf(sw / tw) * scale;
+        es[r][3] = TABLES ? 0.f : logf(sh / th) * scale;
 #pragma unroll
         for (int h = 0; h < HH / 2; ++h) acc[r][h] = bp ? f32x2{bp[2 * h], bp[2 * h + 1]} : f32x2{0.f, 0.f};
     }
 
     // k is a real loop (it only indexes the kernarg table and LDS); c and r are unrolled so that
     // es[][] / acc[][] stay in registers (a fully unrolled body spills: 256 VGPRs + scratch).
+    // per-box tables: [box][coordinate w / h][k][sin, cos] = 32 floats per box (F = 16)
+    const float *ttab = TABLES ? tgt_tab + ((size_t)b * N2 + (jok ? j : N2 - 1)) * (2 * F) : nullptr;
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
         const float d = dim_t.v[k], rd = dim_t.inv[k];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float sn[kRelRows], cs[kRelRows];
+            if (TABLES && c >= 2) {
+                const f32x2 tsc = *reinterpret_cast<const f32x2 *>(ttab + ((c - 2) * K + k) * 2);       // sin, cos of the key box's term
 #pragma unroll
-            for (int r = 0; r < kRelRows; ++r) sincos_cw(div_by_const(es[r][c], d, rd), sn[r], cs[r]);
+                for (int r = 0; r < kRelRows; ++r) {
+                    const int i = (i0 + r < N1) ? i0 + r : N1 - 1;
+                    const float *st = src_tab + ((size_t)b * N1 + i) * (2 * F) + ((c - 2) * K + k) * 2;  // wave-uniform: scalar loads
+                    const float ss = st[0], sc = st[1];
+                    sn[r] = __builtin_fmaf(ss, tsc.y, -(sc * tsc.x));          // sin(a - b) = sin a cos b - cos a sin b
+                    cs[r] = __builtin_fmaf(sc, tsc.y, ss * tsc.x);             // cos(a - b) = cos a cos b + sin a sin b
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < kRelRows; ++r) sincos_cw(div_by_const(es[r][c], d, rd), sn[r], cs[r]);
+            }
             const int ch = c * F + 2 * k;
             f32x2 ws[HH / 2], wc[HH / 2];
 #pragma unroll
@@ -146,6 +164,27 @@ __global__ __launch_bounds__(kRelWaves *kWave) void relation_bias_kernel(
             out[(((size_t)b * HH + 2 * h + 1) * N1 + (i0 + r)) * N2 + j] = a.y > 0.f ? a.y : 0.f;
         }
     }
+}
+
+// Per-box tables for TABLES = true: thread = (box, coordinate, k); the angle (log(size + eps) * scale) / dim_t[k] and its sine /
+// cosine in DOUBLE precision, rounded once -- the fp32 reference rounds log(s1 / s2) * scale / dim_t at |angle| up to 1e3,
+// i.e. to ~3e-5 rad; the table route is within that of it and closer to the exact value (tests hold both to 1e-4 of the
+// fp32 and of the fp64 evaluation of the reference formula).  size + eps is formed in fp32 as the reference does.
+struct DimTD {
+    double v[16];
+};
+__global__ __launch_bounds__(256) void relation_tables_kernel(const float *__restrict__ boxes, long long nboxes, int K, float scale,
+                                                             float eps, DimTD dim_t, float *__restrict__ tab)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nboxes * 2 * K) return;
+    const int k = (int)(idx % K);
+    const int c = (int)((idx / K) % 2);
+    const long long box = idx / (2 * K);
+    const float sz = boxes[box * 4 + 2 + c] + eps;
+    const double a = log((double)sz) * (double)scale / dim_t.v[k];
+    tab[idx * 2] = (float)sin(a);
+    tab[idx * 2 + 1] = (float)cos(a);
 }
 
 // Generic fallback: any even F <= 32, Hh <= 16; one thread per (i, j).
@@ -346,14 +385,46 @@ extern "C" int rdetr_relation_bias_f32(const float *src, const float *tgt, const
         const int rows_per_block = kRelWaves * kRelRows;
         dim3 grid((N2 + kWave - 1) / kWave, (N1 + rows_per_block - 1) / rows_per_block, B), block(kRelWaves * kWave);
         if (grid.y > 65535) return RDETR_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((relation_bias_kernel<16, 8>), grid, block, 0, st, src, tgt, proj_weight, proj_bias, N1, N2,
-                           scale, eps, dt, out);
+        hipLaunchKernelGGL((relation_bias_kernel<16, 8, false>), grid, block, 0, st, src, tgt, proj_weight, proj_bias, N1, N2,
+                           scale, eps, dt, out, nullptr, nullptr);
     } else {
         if (N1 > 65535) return RDETR_ERR_UNSUPPORTED;
         dim3 grid((N2 + 255) / 256, N1, B), block(256);
         hipLaunchKernelGGL(relation_bias_generic_kernel, grid, block, 0, st, src, tgt, proj_weight, proj_bias, N1, N2,
                            Hh, F, scale, eps, dt, out);
     }
+    return launch_status();
+}
+
+extern "C" int rdetr_relation_bias_ws_f32(const float *src, const float *tgt, const float *proj_weight, const float *proj_bias,
+                                          int B, int N1, int N2, int Hh, int F, float scale, float temperature, float eps,
+                                          float *workspace, float *out, void *stream)
+{
+    // the table route serves the model's configuration only; anything else is the plain entry point's business
+    const bool aligned = reinterpret_cast<uintptr_t>(tgt) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 8 == 0;
+    if (!(F == 16 && Hh == 8 && aligned && workspace) || B <= 0 || N1 <= 0 || N2 <= 0 || B > 65535)
+        return rdetr_relation_bias_f32(src, tgt, proj_weight, proj_bias, B, N1, N2, Hh, F, scale, temperature, eps, out, stream);
+    if (!src || !tgt || !proj_weight || !out) return RDETR_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DimT dt;
+    DimTD dtd;
+    for (int k = 0; k < 16; ++k) { dt.v[k] = dt.inv[k] = 1.f; dtd.v[k] = 1.0; }
+    for (int k = 0; k < F / 2; ++k) {
+        dt.v[k] = powf(temperature, (float)k * 2.0f / (float)F);
+        dt.inv[k] = (float)(1.0 / (double)dt.v[k]);
+        dtd.v[k] = (double)dt.v[k];
+    }
+    float *src_tab = workspace, *tgt_tab = workspace + (size_t)B * N1 * 2 * F;
+    const long long n1 = (long long)B * N1, n2 = (long long)B * N2;
+    hipLaunchKernelGGL(relation_tables_kernel, dim3((unsigned)((n1 * F + 255) / 256)), dim3(256), 0, st, src, n1, F / 2, scale, eps, dtd,
+                       src_tab);
+    hipLaunchKernelGGL(relation_tables_kernel, dim3((unsigned)((n2 * F + 255) / 256)), dim3(256), 0, st, tgt, n2, F / 2, scale, eps, dtd,
+                       tgt_tab);
+    const int rows_per_block = kRelWaves * kRelRows;
+    dim3 grid((N2 + kWave - 1) / kWave, (N1 + rows_per_block - 1) / rows_per_block, B), block(kRelWaves * kWave);
+    if (grid.y > 65535) return RDETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((relation_bias_kernel<16, 8, true>), grid, block, 0, st, src, tgt, proj_weight, proj_bias, N1, N2, scale, eps,
+                       dt, out, src_tab, tgt_tab);
     return launch_status();
 }
 

@@ -299,10 +299,12 @@ def relation_bias(src_boxes: torch.Tensor, tgt_boxes: torch.Tensor, proj_weight:
     B, N1, _ = src.shape
     N2 = tgt.shape[1]
     out = torch.empty(B, Hh, N1, N2, dtype=torch.float32, device=src.device)
-    st = _lib.load().rdetr_relation_bias_f32(src.data_ptr(), tgt.data_ptr(), w.data_ptr(),
-                                             None if b is None else b.data_ptr(), B, N1, N2, Hh, num_pos_feats,
-                                             scale, temperature, eps, out.data_ptr(), _stream_ptr(src))
-    _lib.check(st, "rdetr_relation_bias_f32")
+    # workspace for the per-box sine tables of the size-ratio coordinates (used for F = 16, Hh = 8; ignored otherwise)
+    ws = torch.empty((B * N1 + B * N2) * 2 * num_pos_feats, dtype=torch.float32, device=src.device)
+    st = _lib.load().rdetr_relation_bias_ws_f32(src.data_ptr(), tgt.data_ptr(), w.data_ptr(),
+                                                None if b is None else b.data_ptr(), B, N1, N2, Hh, num_pos_feats,
+                                                scale, temperature, eps, ws.data_ptr(), out.data_ptr(), _stream_ptr(src))
+    _lib.check(st, "rdetr_relation_bias_ws_f32")
     return out
 
 

@@ -235,6 +235,14 @@ def test_relation_bias_weight_grad(rd):
     tgt = torch.cat([torch.rand(2, 29, 2, generator=g), torch.rand(2, 29, 2, generator=g) * 0.4 + 0.02], -1)
     rel = rd.PositionRelationEmbedding(16, 8).to(DEV)
     go = torch.randn(2, 8, 33, 29, generator=g)
+    # ReLU is only piecewise differentiable: where the pre-activation is within 1e-3 of zero, which side an implementation
+    # lands on is rounding (the kernel and the fp32 reference differ by ~3e-5 there), so those entries get no gradient
+    # in this comparison -- the analogue of helpers.kink_mask for the bilinear kinks
+    with torch.no_grad():
+        w0, b0 = rel.pos_proj[0].weight.detach().cpu().double(), rel.pos_proj[0].bias.detach().cpu().double()
+        feat = torch_ref.sine_embed(torch_ref.box_rel_encoding(src.double(), tgt.double()))       # [B, N1, N2, 64]
+        pre = torch.einsum("bijc,hc->bhij", feat, w0.view(8, -1)) + b0.view(1, 8, 1, 1)
+        go = go * (pre.abs() > 1e-3)
     rel(src.to(DEV), tgt.to(DEV)).backward(go.to(DEV))
     w = rel.pos_proj[0].weight.detach().cpu().clone().requires_grad_()
     b = rel.pos_proj[0].bias.detach().cpu().clone().requires_grad_()

@@ -10,6 +10,8 @@ optimiser grouping matches on ``sampling_offsets``, optimizer/param_dict.py:82) 
 """
 from __future__ import annotations
 
+import os
+
 import math
 import warnings
 
@@ -110,7 +112,13 @@ class MultiScaleDeformableAttention(nn.Module):
                 "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
         fused = (value.is_cuda and not torch.is_grad_enabled()
                  and ops.msda_fast_path(self.num_heads, self.embed_dim // self.num_heads, self.num_levels, self.num_points))
-        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not fused)
+        # the padding mask inside the kernel costs 4 byte loads per sample: cheaper than a fill pass over the projected
+        # value for the decoder's few hundred queries, dearer for the encoder's Nq == S (measured: +32 us vs -21 us per call)
+        mask_in_kernel = fused and key_padding_mask is not None and query.shape[1] * 4 <= value.shape[1]
+        _force = os.environ.get("RDETR_MASK_IN_KERNEL")          # A/B aid: "always" / "never"
+        if _force and fused and key_padding_mask is not None:
+            mask_in_kernel = _force == "always"
+        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not mask_in_kernel)
         core_dtype = v.dtype if v.dtype in (torch.float32, torch.bfloat16) else torch.float32
         needs_grad = torch.is_grad_enabled() and any(
             t.requires_grad for t in (v, offsets, logits, reference_points))
@@ -119,7 +127,8 @@ class MultiScaleDeformableAttention(nn.Module):
             # padding mask (rows of padded positions count as zero: no fill pass over the projected value)
             core = ops.ms_deform_attn_forward_fused(
                 v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype).contiguous(),
-                logits.to(core_dtype).contiguous(), reference_points.float().contiguous(), key_padding_mask)
+                logits.to(core_dtype).contiguous(), reference_points.float().contiguous(),
+                key_padding_mask if mask_in_kernel else None)
         elif (v.is_cuda and not needs_grad
                 and ops.msda_fast_path(self.num_heads, self.embed_dim // self.num_heads, self.num_levels, self.num_points)):
             core = ops.ms_deform_attn_forward_fused(

@@ -96,6 +96,20 @@ int rdetr_msda_forward_fused_masked_bf16(const uint16_t *value, const int64_t *s
                                          const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
                                          uint16_t *out, void *stream);
 
+/* General fused-producer form: as rdetr_msda_forward_fused_masked_* plus ROW STRIDES (in elements; 0 = contiguous) of the
+ * two projection outputs, so that sampling_offsets and attention_weights can be the column slices [0, 2*H*L*P) and
+ * [2*H*L*P, 3*H*L*P) of ONE [rows, 3*H*L*P] GEMM output (one projection GEMM instead of two).  ld_offsets must be even
+ * (offsets are read as (x, y) pairs). */
+int rdetr_msda_forward_fused_ex_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                    const float *sampling_offsets, int ld_offsets, const float *attn_logits, int ld_logits,
+                                    const float *reference_points, int ref_dim, const uint8_t *key_padding_mask, int B,
+                                    int S, int H, int D, int L, int Nq, int P, float *out, void *stream);
+int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                     const int64_t *level_start_index, const uint16_t *sampling_offsets, int ld_offsets,
+                                     const uint16_t *attn_logits, int ld_logits, const float *reference_points, int ref_dim,
+                                     const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
+                                     uint16_t *out, void *stream);
+
 /* "Planned" forms of the four entry points above (H = 8, D = 32, P = 4 implied; L <= 8): identical
  * arithmetic and results, plus `host_spatial_shapes`, a HOST copy of the [L,2] (h,w) table, so that the launch can
  * be planned around the pyramid geometry (levels packed contiguously, level_start = running sum).  The reference

@@ -25,6 +25,8 @@ SIGNATURES = {
     "rdetr_msda_forward_fused_bf16": [_vp] * 6 + [_c_int] * 8 + [_vp, _vp],
     "rdetr_msda_forward_fused_masked_f32": [_vp] * 6 + [_c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_fused_masked_bf16": [_vp] * 6 + [_c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
+    "rdetr_msda_forward_fused_ex_f32": [_vp] * 4 + [_c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
+    "rdetr_msda_forward_fused_ex_bf16": [_vp] * 4 + [_c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_planned_f32": [_vp] * 6 + [_c_int] * 4 + [_vp, _vp],
     "rdetr_msda_forward_planned_bf16": [_vp] * 6 + [_c_int] * 4 + [_vp, _vp],
     "rdetr_msda_forward_fused_planned_f32": [_vp] * 7 + [_c_int] * 5 + [_vp, _vp],

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
     int L_rt, int Nq, int tiles_per_image, int nblk, int tile2d, T *__restrict__ out,
-    const unsigned char *__restrict__ pad_mask)
+    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
@@ -184,8 +184,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     float pa[kPtsPerLane];
     f32x2 pxy[kPtsPerLane];
     if constexpr (FUSED) {
-        const T *off_q = static_cast<const T *>(src_a) + hrow * 2;
-        const T *lg_q = static_cast<const T *>(src_b) + hrow;
+        // row strides (elements) of the two projection outputs: they may be column slices of ONE [rows, 3*H*L*P] GEMM output
+        const T *off_q = static_cast<const T *>(src_a) + (ld_a ? row * (size_t)ld_a + (size_t)m * LP * 2 : hrow * 2);
+        const T *lg_q = static_cast<const T *>(src_b) + (ld_b ? row * (size_t)ld_b + (size_t)m * LP : hrow);
         float mx = -__builtin_inff();
 #pragma unroll
         for (int k = 0; k < kPtsPerLane; ++k) {
@@ -375,17 +376,18 @@ static char msda_algo()
 template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
-                        int S, int L, int Nq, int tiles, int nblk, int tile2d, T *out, const unsigned char *pad_mask)
+                        int S, int L, int Nq, int tiles, int nblk, int tile2d, T *out, const unsigned char *pad_mask, int ld_a,
+                        int ld_b)
 {
     if (L == 4)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask, ld_a, ld_b);
     else if (L == 5)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask, ld_a, ld_b);
     else
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask, ld_a, ld_b);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
@@ -394,7 +396,7 @@ template <typename T, bool FUSED>
 static int msda_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
                         const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
                         int P, T *out, hipStream_t stream, const int64_t *host_shapes = nullptr, bool force_direct = false,
-                        const unsigned char *pad_mask = nullptr)
+                        const unsigned char *pad_mask = nullptr, int ld_a = 0, int ld_b = 0)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
     if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
@@ -407,7 +409,7 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *le
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
         if constexpr (sizeof(T) == 2) {
-            if (msda_algo() == 'l' && !host_shapes && !force_direct && !pad_mask) {
+            if (msda_algo() == 'l' && !host_shapes && !force_direct && !pad_mask && !ld_a && !ld_b) {
                 const int st = msda_tile_forward<FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, L, Nq,
                                                         out, stream);
                 if (st != RDETR_ERR_UNSUPPORTED) return st;
@@ -431,10 +433,10 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *le
         const long long nblk = (long long)B * H * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
         launch_qrun<T, FUSED>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
-                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, tile2d, out, pad_mask);
+                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, tile2d, out, pad_mask, ld_a, ld_b);
         return launch_status();
     }
-    if (FUSED || pad_mask) return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
+    if (FUSED || pad_mask || ld_a || ld_b) return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
     const long long total = (long long)B * Nq * H * D;
     const long long want = (total + 255) / 256;
     dim3 grid((unsigned)(want < 16384 ? want : 16384)), block(256);
@@ -644,4 +646,34 @@ extern "C" int rdetr_msda_forward_fused_masked_bf16(const uint16_t *value, const
     return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
                                                reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
                                                static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask);
+}
+
+// Fused-producer form, general: optional padding mask and row strides of the two projection outputs.
+extern "C" int rdetr_msda_forward_fused_ex_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                               const float *sampling_offsets, int ld_offsets, const float *attn_logits,
+                                               int ld_logits, const float *reference_points, int ref_dim,
+                                               const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
+                                               float *out, void *stream)
+{
+    if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
+        ld_offsets % 2 != 0)
+        return RDETR_ERR_INVALID_ARG;
+    return rdetr::msda_forward<float, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                            reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                            static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask, ld_offsets, ld_logits);
+}
+
+extern "C" int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spatial_shapes,
+                                                const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                                int ld_offsets, const uint16_t *attn_logits, int ld_logits,
+                                                const float *reference_points, int ref_dim, const uint8_t *key_padding_mask,
+                                                int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream)
+{
+    if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
+        ld_offsets % 2 != 0)
+        return RDETR_ERR_INVALID_ARG;
+    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                               reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                               static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask, ld_offsets,
+                                               ld_logits);
 }

@@ -75,7 +75,21 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.zeros_(self.output_proj.bias)
 
-    def _projections(self, query: Tensor, value: Tensor, key_padding_mask, fill: bool = True):
+    def _merged_query_projection(self):
+        """sampling_offsets and attention_weights as ONE [3*H*L*P, C] projection (inference): both read the same query, so
+        one GEMM writes [rows, 2*H*L*P | H*L*P] and the kernel reads the two column slices in place.  Cached until a
+        parameter changes (the separate nn.Linear modules stay the owners: state_dict keys are the reference's)."""
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.data_ptr(),
+               aw.weight.data_ptr(), so.weight.dtype, so.weight.device)
+        cache = getattr(self, "_merged_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, torch.cat([so.weight, aw.weight], 0).contiguous(), torch.cat([so.bias, aw.bias], 0).contiguous())
+            object.__setattr__(self, "_merged_cache", cache)
+        return cache[1], cache[2]
+
+    def _projections(self, query: Tensor, value: Tensor, key_padding_mask, fill: bool = True, merged: bool = False):
         """value projection (+ padding zero-fill, ms_deform_attn.py:316-321, unless the caller applies the mask itself)
         and the two raw query projections."""
         B, Nq, _ = query.shape
@@ -88,6 +102,13 @@ class MultiScaleDeformableAttention(nn.Module):
             else:                                      # inference: fill the fresh projection in place (no clone pass)
                 v.masked_fill_(key_padding_mask[..., None], float(0))
         v = v.view(B, S, H, self.embed_dim // H)
+        if merged:
+            w, b = self._merged_query_projection()
+            both = torch.nn.functional.linear(query, w, b)                      # [B, Nq, 3*H*L*P]
+            n_off = H * L * P * 2
+            offsets = both[..., :n_off].view(B, Nq, H, L, P, 2)                 # column slices, read in place by the kernel
+            logits = both[..., n_off:].view(B, Nq, H, L * P)
+            return v, offsets, logits
         offsets = self.sampling_offsets(query).view(B, Nq, H, L, P, 2)
         logits = self.attention_weights(query).view(B, Nq, H, L * P)
         return v, offsets, logits
@@ -118,7 +139,8 @@ class MultiScaleDeformableAttention(nn.Module):
         _force = os.environ.get("RDETR_MASK_IN_KERNEL")          # A/B aid: "always" / "never"
         if _force and fused and key_padding_mask is not None:
             mask_in_kernel = _force == "always"
-        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not mask_in_kernel)
+        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not mask_in_kernel,
+                                              merged=fused and os.environ.get("RDETR_MERGED_PROJ", "1") != "0")
         core_dtype = v.dtype if v.dtype in (torch.float32, torch.bfloat16) else torch.float32
         needs_grad = torch.is_grad_enabled() and any(
             t.requires_grad for t in (v, offsets, logits, reference_points))
@@ -126,8 +148,8 @@ class MultiScaleDeformableAttention(nn.Module):
             # inference: softmax + location arithmetic happen inside the gather kernel's set-up phase, and so does the
             # padding mask (rows of padded positions count as zero: no fill pass over the projected value)
             core = ops.ms_deform_attn_forward_fused(
-                v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype).contiguous(),
-                logits.to(core_dtype).contiguous(), reference_points.float().contiguous(),
+                v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype),
+                logits.to(core_dtype), reference_points.float().contiguous(),
                 key_padding_mask if mask_in_kernel else None)
         elif (v.is_cuda and not needs_grad
                 and ops.msda_fast_path(self.num_heads, self.embed_dim // self.num_heads, self.num_levels, self.num_points)):

@@ -131,6 +131,22 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
     return out
 
 
+def _producer_row_stride(t: torch.Tensor):
+    """0 for a contiguous tensor; the row stride (elements) if `t` [B, Nq, ...] is a column slice of a wider row-major
+    matrix (every row contiguous, rows evenly strided, even stride); None if neither."""
+    if t.is_contiguous():
+        return 0
+    inner = 1
+    for d in range(t.dim() - 1, 1, -1):                  # dims after (B, Nq) must be contiguous among themselves
+        if t.shape[d] != 1 and t.stride(d) != inner:
+            return None
+        inner *= t.shape[d]
+    ld = t.stride(1)
+    if ld < inner or ld % 2 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld):
+        return None
+    return ld
+
+
 def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
                                  sampling_offsets: torch.Tensor, attn_logits: torch.Tensor,
                                  reference_points: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -139,8 +155,15 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
     outputs in value's dtype; reference_points [B,Nq,L,2|4] fp32 -> [B,Nq,H*D] in value's dtype.
     Same result as softmax + sampling-location arithmetic + ms_deform_attn_forward (ms_deform_attn.py:322-370)."""
     _require_device(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points)
+    # the two projection outputs may be column slices of one wider GEMM output (rows evenly strided, each row contiguous)
+    ld_off = _producer_row_stride(sampling_offsets)
+    ld_lg = _producer_row_stride(attn_logits)
+    if ld_off is None:
+        sampling_offsets, ld_off = sampling_offsets.contiguous(), 0
+    if ld_lg is None:
+        attn_logits, ld_lg = attn_logits.contiguous(), 0
     _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                        sampling_offsets=sampling_offsets, attn_logits=attn_logits, reference_points=reference_points)
+                        reference_points=reference_points)
     if value.dim() != 4 or sampling_offsets.dim() != 6 or reference_points.dim() != 4:
         raise _lib.RdetrError("expected value [B,S,H,D], sampling_offsets [B,Nq,H,L,P,2], reference_points [B,Nq,L,2|4]")
     B, S, H, D = value.shape
@@ -163,6 +186,21 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
     else:
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if ld_off or ld_lg:                 # strided producer rows (merged projection), optional padding mask
+        mask_ptr = None
+        if key_padding_mask is not None:
+            _require_device(key_padding_mask)
+            if tuple(key_padding_mask.shape) != (B, S):
+                raise _lib.RdetrError("key_padding_mask must be [B, S]")
+            mask_u8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool \
+                else key_padding_mask.to(torch.uint8).contiguous()
+            mask_ptr = mask_u8.data_ptr()
+        fx = lib.rdetr_msda_forward_fused_ex_f32 if value.dtype == torch.float32 else lib.rdetr_msda_forward_fused_ex_bf16
+        st = fx(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(), ld_off,
+                attn_logits.data_ptr(), ld_lg, reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P,
+                out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_fused_ex")
+        return out
     if key_padding_mask is not None:
         # `value` is the UNFILLED projection: the kernel treats the rows of padded positions as zero (bool [B, S], True = padded)
         _require_device(key_padding_mask)

@@ -500,3 +500,33 @@ def test_msda_fused_padding_mask_inside_kernel(rd, dtype, ref_dim):
     assert torch.equal(got, want)
     none = rd.ms_deform_attn_forward_fused(dev(value), dev(shp), dev(start), dev(off), dev(logits), dev(ref))
     assert not torch.equal(got, none)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_msda_fused_strided_producer_rows(dtype, with_mask):
+    """offsets / logits as column slices of ONE [rows, 3*H*L*P] projection output (rdetr_msda_forward_fused_ex_*):
+    bit-identical to the same numbers handed over as two contiguous tensors."""
+    from relation_detr_amd import ops
+    torch.manual_seed(11)
+    dev = "cuda"
+    B, H, D, L, P = 2, 8, 32, 4, 4
+    shapes = torch.tensor([[20, 27], [10, 14], [5, 7], [3, 4]], device=dev)
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    for Nq in (S, 37):
+        value = torch.randn(B, S, H, D, device=dev).to(dtype)
+        both = (torch.randn(B, Nq, 3 * H * L * P, device=dev) * 2).to(dtype)
+        n_off = H * L * P * 2
+        off_v = both[..., :n_off].view(B, Nq, H, L, P, 2)
+        lg_v = both[..., n_off:].view(B, Nq, H, L * P)
+        assert not off_v.is_contiguous() and ops._producer_row_stride(off_v) == 3 * H * L * P
+        ref = torch.rand(B, Nq, L, 4, device=dev) * 0.8 + 0.1
+        mask = (torch.rand(B, S, device=dev) < 0.2) if with_mask else None
+        got = ops.ms_deform_attn_forward_fused(value, shapes, start, off_v, lg_v, ref, mask)
+        want = ops.ms_deform_attn_forward_fused(value, shapes, start, off_v.contiguous(), lg_v.contiguous(), ref, mask)
+        assert torch.equal(got, want)
+    # a slice whose rows are not evenly strided falls back to a copy, not to a wrong read
+    odd = torch.randn(B, 37, H, L, P, 4, device=dev).to(dtype)[..., ::2]
+    assert ops._producer_row_stride(odd) is None

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
     int splits, int nblk, int dbg, int rect_cfg, uint16_t *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    extern __shared__ __attribute__((aligned(64))) unsigned char lds[];
     TileShared &sh = *reinterpret_cast<TileShared *>(lds);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,21 +228,24 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(plane), 0, (unsigned)S * kTlGPixB - (unsigned)m * kTlPixB, 0x00020000);
 
-    // set-up role: query qx of the wave, point pp.   gather role: lane group g, row tq / piece tp of a transposed read;
-    // as an A-operand lane: row am = lane & 15 = 4 * (its group) + ar
+    // set-up role: query qx of the wave, point pp.   gather role: K-group g, row tq / piece tp of a transposed read;
+    // as an A-operand lane: row am = lane & 15 = 8 * (quad half ah) + 2 * (K-group ag) + (0 = bf16 high part, 1 = low part)
     const int qx = lane >> 2, pp = lane & 3;
     const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-    const int am = lane & 15, ar = am & 3;
-    const bool a_active = (am >> 2) == g;
+    const int am = lane & 15, ah = am >> 3, ag = (am >> 1) & 3, apart = am & 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;     // 0 in practice
     const unsigned stage_off = (unsigned)(kTlStageOff + wave * kTlStagePerWave);
     unsigned char *stage = lds + stage_off;
-    const unsigned o_rd = stage_off + (unsigned)(g * 128 + tq * 4);                       // O[2g][.][tq]; + o' * 512 + p * 16
-    // A operand = {low 8 bytes: k = 8g .. 8g+3 (sample 2g), high 8 bytes: k = 8g+4 .. (sample 2g+1)}: an active lane reads
-    // its sample's 4 weights (hi or lo part) into the matching half and zeros into the other; idle lanes read zeros twice
-    const unsigned w_real = stage_off + 1024u + (unsigned)((2 * g + (ar & 1)) * 64 + (ar >> 1) * 8);
-    const unsigned w_rd_lo = (a_active && !(ar & 1)) ? w_real : (unsigned)kTlZeroKOff;
-    const unsigned w_rd_hi = (a_active && (ar & 1)) ? w_real : (unsigned)kTlZeroKOff;
-    const unsigned c0 = (unsigned)(tp * 8 + (g & 1) * 32);
+    // staging of one pass: [0, 1K) O[query][corner][point] u32 LDS row offsets (the +32 of the odd queries' channel-half
+    // swizzle included), [1K, 2K) W[query][part][point][corner] bf16 weights.  One MFMA step = octet o', quad half h, point
+    // pair j: K-group g carries the two samples (points 2j, 2j + 1) of query 8 o' + 4 h + g.
+    const unsigned o_rd = lds0 + stage_off + (unsigned)(g * 64 + tq * 16);                 // + o' * 512 + h * 256: all 4 points
+    // A operand: lane (row am, K-group g) is live only in the steps of its own quad half and only if its row's query is the
+    // K-group's -- then it reads that query's 2 x 4 weights (16 B); otherwise 16 B of zeros.  + o' * 512 + j * 16
+    const unsigned w_real = lds0 + stage_off + 1024u + (unsigned)((4 * ah + g) * 64 + apart * 32);
+    const unsigned w_rd0 = (ag == g && ah == 0) ? w_real : lds0 + (unsigned)kTlZeroKOff;
+    const unsigned w_rd1 = (ag == g && ah == 1) ? w_real : lds0 + (unsigned)kTlZeroKOff;
+    const unsigned c0 = lds0 + (unsigned)(tp * 8);
     unsigned char *fgo = lds + kTlFgoOff + wave * 64;
 
     // ---- helpers -----------------------------------------------------------------------------------------------
@@ -418,21 +421,19 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         }
     };
 
-    f32x4 acc[2][2];                       // [octet o'][X]: D[4g + r][channel i + 16 ((g & 1) ^ X)] of queries 8 o' + 2g + (r & 1)
+    f32x4 acc[2][2];                       // [octet o'][X]: D rows 4g + r of a lane = query 8 o' + 2g + (r >> 1), part r & 1,
+                                           // channel (lane & 15) + 16 ((r >> 1) ^ X)
 
-    // one MFMA step: 8 samples (queries 8 o' .. 8 o' + 7, point p) x 32 channels.
-    // oa / ob = LDS offsets of this lane's row (corner tq) of samples 2g / 2g + 1
-    auto mfma_step = [&](int op, int p, unsigned oa, unsigned ob, f32x4 &d0, f32x4 &d1) {
-        const u32x2 alo = *reinterpret_cast<const u32x2 *>(lds + w_rd_lo + op * 512 + p * 16);
-        const u32x2 ahi = *reinterpret_cast<const u32x2 *>(lds + w_rd_hi + op * 512 + p * 16);
-        const u32x4 af = {alo.x, alo.y, ahi.x, ahi.y};
+    auto lds_b128 = [](unsigned a) { return *(__attribute__((address_space(3))) const u32x4 *)a; };
+    auto lds_tr = [](unsigned a) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tl_s16x4 *)a));
+    };
+    // one MFMA step: 4 queries x 2 points (8 samples) x 32 channels.  `wa` = LDS address of this lane's 16 bytes of the
+    // A operand; oa / ob = LDS offsets of this lane's row (corner tq) of its K-group's two samples
+    auto mfma_step = [&](unsigned wa, unsigned oa, unsigned ob, f32x4 &d0, f32x4 &d1) {
+        const u32x4 af = lds_b128(wa);
         const unsigned ba = oa + c0, bb = ob + c0;
-        const tl_s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tl_s16x4 *)(lds + ba));
-        const tl_s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tl_s16x4 *)(lds + bb));
-        const tl_s16x4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tl_s16x4 *)(lds + (ba ^ 32u)));
-        const tl_s16x4 r3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tl_s16x4 *)(lds + (bb ^ 32u)));
-        const u32x2 x0 = __builtin_bit_cast(u32x2, r0), x1 = __builtin_bit_cast(u32x2, r1);
-        const u32x2 y0 = __builtin_bit_cast(u32x2, r2), y1 = __builtin_bit_cast(u32x2, r3);
+        const u32x2 x0 = lds_tr(ba), x1 = lds_tr(bb), y0 = lds_tr(ba ^ 32u), y1 = lds_tr(bb ^ 32u);
         const u32x4 b0 = {x0.x, x0.y, x1.x, x1.y}, b1 = {y0.x, y0.y, y1.x, y1.y};
         d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, af), __builtin_bit_cast(tl_bf16x8, b0), d0, 0, 0, 0);
         d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tl_bf16x8, af), __builtin_bit_cast(tl_bf16x8, b1), d1, 0, 0, 0);
@@ -449,17 +450,23 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         const TileCorner c = tl_corners(sm.xy[l], sm.a[l], sm.q >= 0, W, H);
         const bool in_rect = c.xa >= rx && c.xb < rx + rw && c.ya >= ry && c.yb < ry + rh;
         const bool flagged = c.inside && !in_rect;
-        u32x4 o = {kTlZeroOff, kTlZeroOff, kTlZeroOff, kTlZeroOff};
+        const unsigned zrow = (unsigned)kTlZeroOff + (unsigned)(qx & 1) * 32u;       // odd queries read the other channel half first
+        u32x4 o = {zrow, zrow, zrow, zrow};
         if (c.inside && in_rect) {           // LDS byte offsets inside the rect
-            const unsigned o00 = buf + (unsigned)((c.ya - ry) * rw + (c.xa - rx)) * kTlPixB;
+            const unsigned o00 = buf + (unsigned)(qx & 1) * 32u + (unsigned)((c.ya - ry) * rw + (c.xa - rx)) * kTlPixB;
             const unsigned dx = (unsigned)(c.xb - c.xa) * kTlPixB, dy = (unsigned)(c.yb - c.ya) * (unsigned)rw * kTlPixB;
             o = u32x4{o00, o00 + dx, o00 + dy, o00 + dy + dx};
         }
         unsigned h01, h23, l01, l23;
         tl_split2(c.w00, c.w01, h01, l01);
         tl_split2(c.w10, c.w11, h23, l23);
-        *reinterpret_cast<u32x4 *>(stage + lane * 16) = o;
-        *reinterpret_cast<u32x4 *>(stage + 1024 + lane * 16) = u32x4{h01, h23, l01, l23};
+        {
+            unsigned *so = reinterpret_cast<unsigned *>(stage + qx * 64 + pp * 4);       // O[query][corner][point]
+            so[0] = o.x; so[4] = o.y; so[8] = o.z; so[12] = o.w;
+            u32x2 *sw = reinterpret_cast<u32x2 *>(stage + 1024 + qx * 64 + pp * 8);     // W[query][part][point][corner]
+            sw[0] = u32x2{h01, h23};
+            sw[4] = u32x2{l01, l23};
+        }
         unsigned long long fmask = __ballot(flagged);          // remaining flagged samples (bit = set-up lane = query * 4 + point)
 
         // flagged samples: publish the global byte offsets of four of them, start their row loads (lane = sample g,
@@ -486,19 +493,17 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         after_setup();                       // the locations are consumed: pass 3 starts loading the next tile's here
 
-        // four steps' row offsets at a time (one LDS round trip per octet), then the transposed reads and MFMAs stream
+        // per (octet, quad half): one 16-byte read brings the row offsets of all four points, then two steps
         if (!(dbg & 32))
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
-            unsigned soa[4], sob[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const unsigned *orow = reinterpret_cast<const unsigned *>(lds + o_rd + op * 512 + p * 16);
-                soa[p] = orow[0];
-                sob[p] = orow[16];
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 so = lds_b128(o_rd + op * 512 + h * 256);
+                const unsigned wa = (h ? w_rd1 : w_rd0) + op * 512;
+                mfma_step(wa, so.x, so.y, acc[op][0], acc[op][1]);
+                mfma_step(wa + 16, so.z, so.w, acc[op][0], acc[op][1]);
             }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) mfma_step(op, p, soa[p], sob[p], acc[op][0], acc[op][1]);
         }
 
         // patch steps: the rows of up to four flagged samples at a time go into the (now dead) offset area, then one MFMA
@@ -516,12 +521,14 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
                 if (fmask == 0ull) break;                        // uniform
                 const int id = __builtin_ctzll(fmask);           // set-up lane = query * 4 + point
                 fmask &= fmask - 1;
-                const int fq = id >> 2, fp = id & 3, fs = fq & 7;
-                const unsigned prow = stage_off + (unsigned)(k * 256 + tq * 64);
-                const unsigned oa = (g == (fs >> 1) && !(fs & 1)) ? prow : (unsigned)kTlZeroOff;
-                const unsigned ob = (g == (fs >> 1) && (fs & 1)) ? prow : (unsigned)kTlZeroOff;
-                if (fq < 8) mfma_step(0, fp, oa, ob, acc[0][0], acc[0][1]);
-                else mfma_step(1, fp, oa, ob, acc[1][0], acc[1][1]);
+                const int fq = id >> 2, fp = id & 3;               // its step: octet fq >> 3, quad half (fq >> 2) & 1, pair fp >> 1
+                const unsigned zr = (unsigned)kTlZeroOff + (unsigned)(g & 1) * 32u;
+                const unsigned prow = stage_off + (unsigned)(k * 256 + tq * 64) + (unsigned)(g & 1) * 32u;
+                const unsigned oa = (g == (fq & 3) && !(fp & 1)) ? prow : zr;
+                const unsigned ob = (g == (fq & 3) && (fp & 1)) ? prow : zr;
+                const unsigned wa = ((fq & 4) ? w_rd1 : w_rd0) + (unsigned)((fp >> 1) * 16);
+                if (fq < 8) mfma_step(wa, oa, ob, acc[0][0], acc[0][1]);
+                else mfma_step(wa + 512, oa, ob, acc[1][0], acc[1][1]);
             }
             done += 4;
             if (fmask != 0ull) issue_patch_loads(done);          // more than four: next batch (its latency is exposed; rare)
@@ -541,9 +548,8 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
                 const f32x4 d = acc[op][X];
-                const int ch = (lane & 15) + 16 * ((g & 1) ^ X);
-                tr[(8 * op + 2 * g) * 32 + ch] = d.x + d.z;
-                tr[(8 * op + 2 * g + 1) * 32 + ch] = d.y + d.w;
+                tr[(8 * op + 2 * g) * 32 + (lane & 15) + 16 * X] = d.x + d.y;
+                tr[(8 * op + 2 * g + 1) * 32 + (lane & 15) + 16 * (X ^ 1)] = d.z + d.w;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

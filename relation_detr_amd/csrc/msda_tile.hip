@@ -49,7 +49,10 @@ constexpr int kTlCoarseSlots = (kTlWaves - kTlCoarseWave0) * 16;
 constexpr int kTlHeads = 8, kTlHeadDim = 32, kTlPoints = 4, kTlLevels = 4;
 constexpr unsigned kTlPixB = 64;                              // LDS bytes per pixel (one bf16 head row)
 constexpr unsigned kTlGPixB = kTlHeads * kTlHeadDim * 2;      // global bytes per pixel (512)
-constexpr int kTlMiscBytes = 3072;
+constexpr int kTlRing = 16;                                // tiles whose geometry / window tables are kept (ring)
+constexpr int kTlGeoOff = 3072;                             // int geo[kTlRing][20]
+constexpr int kTlDescOff = kTlGeoOff + kTlRing * 80;        // int desc[kTlRing][4 levels][4]
+constexpr int kTlMiscBytes = kTlDescOff + kTlRing * 64;     // 5376
 constexpr int kTlZeroOff = 512;                               // 64 zero bytes (inside the misc area): the "zero row"
 constexpr int kTlFgoOff = 1024;                               // 16 waves x 64 B: global row offsets of the flagged samples in flight
 constexpr int kTlZeroKOff = 2048 + 32;                        // ~1 KiB of zeros (from 2048): what the idle lanes of an A operand read;
@@ -59,17 +62,18 @@ constexpr int kTlStagePerWave = 2048;                         // [0,1K) row offs
 constexpr int kTlBufAOff = kTlStageOff + kTlWaves * kTlStagePerWave;
 constexpr int kTlCapA = 1344, kTlSqWA = 38, kTlSqHA = 28;     // buffer capacity in pixels; window of level 0 (level 1: 30 x 28)
 constexpr int kTlBufBOff = kTlBufAOff + kTlCapA * (int)kTlPixB;
-constexpr int kTlCapB = 656, kTlSqWB = 22, kTlSqHB = 21;      // window of levels 2 / 3 (a level that fits is taken whole)
+constexpr int kTlCapB = 620, kTlSqWB = 22, kTlSqHB = 21;      // window of levels 2 / 3 (a level that fits is taken whole)
 constexpr int kTlLdsBytes = kTlBufBOff + kTlCapB * (int)kTlPixB;
-static_assert(kTlLdsBytes == 160 * 1024, "LDS map must fill exactly 160 KiB");
+static_assert(kTlLdsBytes <= 160 * 1024 && kTlLdsBytes > 160 * 1024 - 64, "LDS map must fill exactly 160 KiB");
 
 struct TileShared {
     int h[kTlLevels], w[kTlLevels], start[kTlLevels];
     int regions_x, regions_y, chunks;      // spatial tiles of level 0; coarse-query chunks per region (1 unless > 64 coarse)
     int max_coarse;
-    int geo[2][20];                        // per tile parity: rx, ry, chunk, -, then per coarser level: xa, ya, nx, n, 2^16 / nx
-    int desc[2][kTlLevels][4];             // per tile parity and level: rect x, y, width (== 2 mod 4), height (0 = none)
 };
+// ring tables (kTlGeoOff / kTlDescOff), entry = tile & (kTlRing - 1):
+//   geo[20]      rx, ry, chunk, -, then per coarser level: xa, ya, nx, n, 2^16 / nx
+//   desc[4][4]   per level: rect x, y, width (== 2 mod 4), height (0 = none)
 static_assert(sizeof(TileShared) <= kTlZeroOff, "tables overlap the zero row");
 
 struct TileSamples {                       // lane (query = lane >> 2, point = lane & 3): its sample in each level
@@ -160,6 +164,8 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
 {
     extern __shared__ __attribute__((aligned(64))) unsigned char lds[];
     TileShared &sh = *reinterpret_cast<TileShared *>(lds);
+    int *const geo_tab = reinterpret_cast<int *>(lds + kTlGeoOff);
+    int *const desc_tab = reinterpret_cast<int *>(lds + kTlDescOff);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     auto compute_geometry = [&](int t, int k) {        // k = lane of the computing wave, 0 .. 15
         const int region = (int)tl_div((unsigned)t, (unsigned)chunks), chunk = t - region * chunks;
         const int ry = (int)tl_div((unsigned)region, (unsigned)regions_x), rx = region - ry * regions_x;
-        int *geo = sh.geo[t & 1];
+        int *geo = geo_tab + (t & (kTlRing - 1)) * 20;
         if (k == 0) { geo[0] = rx; geo[1] = ry; geo[2] = chunk; }
         if (k >= 1 && k < kTlLevels) {
             const int l = k;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
 
     // query owned by lane >> 2 of this wave in tile t (-1 = none)
     auto query_of = [&](int t) -> int {
-        const int *geo = sh.geo[t & 1];
+        const int *geo = geo_tab + (t & (kTlRing - 1)) * 20;
         const int rx = __builtin_amdgcn_readfirstlane(geo[0]), ry = __builtin_amdgcn_readfirstlane(geo[1]);
         const int chunk = __builtin_amdgcn_readfirstlane(geo[2]);
         if (wave < kTlCoarseWave0) {
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     // data-driven bounding box per tile was a quarter of the kernel's time and came out clipped to these sizes anyway);
     // whatever a window misses is flagged and patched, so this is a speed heuristic only.
     auto fixed_desc = [&](int l, int t) {
-        const int *geo = sh.geo[t & 1];
+        const int *geo = geo_tab + (t & (kTlRing - 1)) * 20;
         int fx0, fx1, fy0, fy1;                        // footprint [fx0, fx1) x [fy0, fy1)
         if (l == 0) {
             fx0 = geo[0] * kTlRegW; fx1 = fx0 + kTlRegW;
@@ -378,18 +384,20 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         const int mx = W - rw, my = H - rh;
         rx = rx > mx ? mx : rx; rx = rx < 0 ? 0 : rx;
         ry = ry > my ? my : ry; ry = ry < 0 ? 0 : ry;
-        sh.desc[t & 1][l][0] = rx;
-        sh.desc[t & 1][l][1] = ry;
-        sh.desc[t & 1][l][2] = rw;
-        sh.desc[t & 1][l][3] = rh;
+        int *d = desc_tab + (t & (kTlRing - 1)) * 16 + l * 4;
+        d[0] = rx;
+        d[1] = ry;
+        d[2] = rw;
+        d[3] = rh;
     };
 
     // DMA the rect of level l (tile parity par) into its buffer: lane = (pixel, 16-byte chunk), 16 pixels per instruction
     auto fill = [&](int l, int par) {
-        const int rx = __builtin_amdgcn_readfirstlane(sh.desc[par][l][0]);
-        const int ry = __builtin_amdgcn_readfirstlane(sh.desc[par][l][1]);
-        const int rw = __builtin_amdgcn_readfirstlane(sh.desc[par][l][2]);
-        const int rh = __builtin_amdgcn_readfirstlane(sh.desc[par][l][3]);
+        const int *dsc = desc_tab + (par & (kTlRing - 1)) * 16 + l * 4;        // par = the tile
+        const int rx = __builtin_amdgcn_readfirstlane(dsc[0]);
+        const int ry = __builtin_amdgcn_readfirstlane(dsc[1]);
+        const int rw = __builtin_amdgcn_readfirstlane(dsc[2]);
+        const int rh = __builtin_amdgcn_readfirstlane(dsc[3]);
         const int W = LW[l], st = LS[l];
         const unsigned buf = l < 2 ? (unsigned)kTlBufAOff : (unsigned)kTlBufBOff;
         const int n4 = rw * rh * 4;
@@ -441,10 +449,11 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
 
     // one level of the wave's 16 queries: set-up (lane = query x point) -> staging -> MFMA loop -> patch steps for flagged samples
     auto pass = [&](int l, int par, const TileSamples &sm, auto &&after_setup) {
-        const int rx = __builtin_amdgcn_readfirstlane(sh.desc[par][l][0]);
-        const int ry = __builtin_amdgcn_readfirstlane(sh.desc[par][l][1]);
-        const int rw = __builtin_amdgcn_readfirstlane(sh.desc[par][l][2]);
-        const int rh = __builtin_amdgcn_readfirstlane(sh.desc[par][l][3]);
+        const int *dsc = desc_tab + (par & (kTlRing - 1)) * 16 + l * 4;        // par = the tile
+        const int rx = __builtin_amdgcn_readfirstlane(dsc[0]);
+        const int ry = __builtin_amdgcn_readfirstlane(dsc[1]);
+        const int rw = __builtin_amdgcn_readfirstlane(dsc[2]);
+        const int rh = __builtin_amdgcn_readfirstlane(dsc[3]);
         const int W = LW[l], H = LH[l];
         const unsigned buf = l < 2 ? (unsigned)kTlBufAOff : (unsigned)kTlBufBOff;
         const TileCorner c = tl_corners(sm.xy[l], sm.a[l], sm.q >= 0, W, H);
@@ -570,23 +579,27 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
     };
 
     // ---- pipeline ----------------------------------------------------------------------------------------------
-    if (wave == 0 && lane < 16) {
-        compute_geometry(t0, lane);
-        if (t0 + 1 < t1) compute_geometry(t0 + 1, lane);
-    }
+    // Tile geometry and window tables are computed for 8 tiles at a time, 16 lanes per tile (the arithmetic is a serial
+    // chain of a few hundred instructions: done per tile by one wave it delayed every barrier of the tile by ~1.5 us)
+    auto tables_for = [&](int t, int k) {                    // 16 consecutive lanes of one wave per tile
+        if (t < t1) compute_geometry(t, k);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (t < t1 && k < kTlLevels) fixed_desc(k, t);
+    };
+    if (tid < kTlRing * 16) tables_for(t0 + (tid >> 4), tid & 15);
     __syncthreads();
     TileSamples cur;                       // ONE register set: the next tile's locations are loaded in pass 3, after the
     load_samples(t0, cur);                 // last set-up of the current tile has consumed them (a second set spills)
 #pragma unroll
     for (int l = 0; l < kTlLevels; ++l) asm volatile("" ::"v"(cur.xy[l].x), "v"(cur.xy[l].y), "v"(cur.a[l]));   // retire the loads (see pass 3)
-    if (tid < kTlLevels) fixed_desc(tid, t0);
-    __syncthreads();
-    fill(0, t0 & 1);
+    fill(0, t0);
     tl_dma_wait();
     __syncthreads();
 
     for (int t = t0; t < t1; ++t) {
-        const int par = t & 1;
+        const int par = t;
         const bool has_next = t + 1 < t1;
         const bool busy = __ballot(cur.q >= 0) != 0ull;  // any query in this wave?
 #pragma unroll
@@ -605,13 +618,12 @@ __global__ __launch_bounds__(kTlThreads) void msda_fwd_tile_kernel(
         __syncthreads();
 
         if (!(dbg & 2)) fill(3, par);                                   // pass 2: level 1 from A   | level 3 -> B in flight
-        if (has_next && tid < kTlLevels) fixed_desc(tid, t + 1);
         if (busy && !(dbg & 4)) pass(1, par, cur, [] {});
         tl_dma_wait();
         __syncthreads();
 
-        if (t + 2 < t1 && wave == 1 && lane < 16) compute_geometry(t + 2, lane);       // read from pass 0 of tile t + 1 on
-        if (has_next && !(dbg & 2)) fill(0, par ^ 1);                 // pass 3: level 3 from B   | next tile's level 0 -> A in flight
+        if (t > t0 && ((t - t0) & 7) == 0 && tid < 128) tables_for(t + 8 + (tid >> 4), tid & 15);      // entries of tiles t - 8 .. t - 1 are dead
+        if (has_next && !(dbg & 2)) fill(0, t + 1);                 // pass 3: level 3 from B   | next tile's level 0 -> A in flight
         const int sq = cur.q;
         bool loaded = false;
         if (busy && !(dbg & 4)) {

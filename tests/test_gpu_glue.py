@@ -86,6 +86,52 @@ def test_graph_replay_matches_eager(dtype):
         assert torch.equal(eager, replay)
 
 
+def test_image_groups_on_parallel_streams_match_one_stream():
+    """ImageGroups: the batch as two image groups on two HIP streams -- eager and inside a captured graph -- gives every
+    image the result of the one-stream run (fp32: the per-image arithmetic does not depend on the group size except for
+    the library GEMMs' tiling, hence a tolerance instead of bit equality)."""
+    from relation_detr_amd import _lib
+    from relation_detr_amd.graph import GraphedCall, ImageGroups
+    from relation_detr_amd.transformer import build_relation_transformer
+    torch.manual_seed(0)
+    shapes = [(40, 56), (20, 28), (10, 14), (5, 7)]
+    net = build_relation_transformer(num_classes=17, d_ffn=128, enc_layers=2, dec_layers=2, num_queries=50,
+                                     hybrid_num_proposals=60).eval().to(DEV)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "sampling_offsets"):
+                m.sampling_offsets.weight.normal_(0, 0.02)
+                m.attention_weights.weight.normal_(0, 0.05)
+    B, L = 4, len(shapes)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(B, 256, h, w, generator=g).to(DEV) for h, w in shapes]
+    pos = [torch.randn(B, 256, h, w, generator=g).to(DEV) for h, w in shapes]
+    masks = []
+    for h, w in shapes:
+        m = torch.zeros(B, h, w, dtype=torch.bool)
+        m[1, :, int(w * 0.8):] = True
+        m[3, int(h * 0.7):, :] = True
+        masks.append(m.to(DEV))
+    inputs = [*feats, *masks, *pos]
+
+    @torch.no_grad()
+    def forward(*t):
+        classes, coords, _, _ = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))
+        return classes[-1], coords[-1]
+
+    want = [x.clone() for x in forward(*inputs)]
+    two = ImageGroups(forward, 2, device=DEV)
+    got = [x.clone() for x in two(*inputs)]
+    replay = [x.clone() for x in GraphedCall(two, inputs)(*inputs)]
+    torch.cuda.synchronize()
+    for w_, g_, r_ in zip(want, got, replay):
+        assert g_.shape == w_.shape
+        assert torch.allclose(g_, w_, atol=2e-4, rtol=1e-4)
+        assert torch.allclose(r_, w_, atol=2e-4, rtol=1e-4)
+    with pytest.raises(_lib.RdetrError):
+        ImageGroups(forward, 3, device=DEV)(*inputs)
+
+
 # ------------------------------------------------------------------------------------------ fused decoder self-attention
 def _attn_reference(q, k, v, H, bias, mask, scale):
     """fp32 softmax(QK^T * scale + bias) V on the bf16-rounded inputs (the arithmetic of relation_transformer.py:452-461

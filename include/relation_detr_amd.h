@@ -266,6 +266,26 @@ int rdetr_box_refine_f32(const void *delta, int delta_is_bf16, const float *ref,
 int rdetr_sine_pos_embed(const float *pos, long long rows, int n, int F, float temperature, float scale, void *out,
                          int out_is_bf16, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * One-pass steps of the encoder's input / output side (each replaces a torch chain that made 2-3 passes over a [B,S,C] tensor).
+ *   rdetr_zero_masked_rows  x.masked_fill_(mask[..., None], 0) in place: the padding fill of the projected value
+ *                           (models/bricks/ms_deform_attn.py:316-319).  x: rows of row_bytes bytes, ld_bytes apart (both
+ *                           multiples of 16, x 16-byte aligned), mask: one byte per row (non-zero = padded).  Only the padded
+ *                           rows are written.
+ *   rdetr_row_max           out[r] = max(x[r, 0..C)) (NaN propagates), x fp32 or bf16 [rows, C] with row stride ldx, out
+ *                           [rows] in x's type: the class-score maximum of the two-stage query selection
+ *                           (models/bricks/relation_transformer.py:105).
+ *   rdetr_nchw_to_tokens    one pyramid level src [B, C, P] (P = H*W) -> out[b, p, c] = src[b, c, p] (+ add_vec[c]), i.e.
+ *                           x.flatten(2).transpose(1, 2) (+ the level embedding, relation_transformer.py:87-89) written
+ *                           straight into the level's rows of the level-packed token tensor (base_transformer.py:17-23):
+ *                           `out` points at the level's first row of image 0; rows are ld_out elements apart (>= C), images
+ *                           out_image_stride elements.  add_vec nullable. */
+int rdetr_zero_masked_rows(void *x, const unsigned char *mask, long long rows, int row_bytes, long long ld_bytes,
+                           void *stream);
+int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long ldx, void *out, void *stream);
+int rdetr_nchw_to_tokens(const void *src, const void *add_vec, int is_bf16, int B, int C, int P,
+                         long long out_image_stride, long long ld_out, void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,9 @@ SIGNATURES = {
     "rdetr_relation_attention_bf16": [_vp] * 3 + [_c_int] * 3 + [_vp, _vp] + [_c_int] * 5 + [_c_float, _vp, _c_int, _vp],
     "rdetr_box_refine_f32": [_vp, _c_int, _vp, _c_ll, _c_float, _vp, _vp],
     "rdetr_sine_pos_embed": [_vp, _c_ll, _c_int, _c_int, _c_float, _c_float, _vp, _c_int, _vp],
+    "rdetr_zero_masked_rows": [_vp, _vp, _c_ll, _c_int, _c_ll, _vp],
+    "rdetr_row_max": [_vp, _c_int, _c_ll, _c_int, _c_ll, _vp, _vp],
+    "rdetr_nchw_to_tokens": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _vp, _vp],
     "rdetr_add_layernorm_f32": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
     "rdetr_add_layernorm_bf16": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
     "rdetr_add_layernorm_strided_f32": [_vp] * 4 + [_c_ll, _c_int, _c_ll, _c_ll, _c_ll, _c_float, _vp, _vp],

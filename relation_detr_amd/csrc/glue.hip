@@ -8,6 +8,14 @@
 //                   (models/bricks/position_encoding.py:115-138): [rows, n] -> [rows, n * F], coordinate order (y, x, rest),
 //                   channel = coord * F + 2k + {sin, cos};  (pos * scale) / dim_t[k] in fp32 as the reference rounds it
 // Bound: launch latency (tens of KB of traffic).
+//
+// and of the encoder's input / output side (HBM-bound, each one pass over its tensor):
+//   zero_masked_rows   value.masked_fill(key_padding_mask[..., None], 0) in place (models/bricks/ms_deform_attn.py:316-319):
+//                      reads the mask, WRITES ONLY the padded rows (torch's masked_fill reads and rewrites every row)
+//   row_max            x.max(-1)[0] of the two-stage class logits (models/bricks/relation_transformer.py:105): 4 rows per wave
+//   nchw_to_tokens     x.flatten(2).transpose(1, 2) of one pyramid level (+ a per-channel vector: the level embedding of
+//                      models/bricks/relation_transformer.py:87-89) written into its row range of the level-packed
+//                      [B, S, C] token tensor (models/bricks/base_transformer.py:17-23): LDS-tiled transpose, 64 x 64
 #include "common.h"
 
 namespace rdetr {
@@ -57,6 +65,67 @@ __global__ __launch_bounds__(256) void sine_pos_embed_kernel(const float *__rest
     glue_store<TO>(o + 1, cosf(a));
 }
 
+
+// ---- zero the rows whose mask byte is set ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_masked_rows_kernel(unsigned char *__restrict__ x, const unsigned char *__restrict__ mask,
+                                                               long long rows, int row_bytes, long long ld_bytes)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;     // 64 rows per wave: lane = row
+    const long long row = row0 + lane;
+    unsigned long long todo = __ballot(row < rows && mask[row] != 0);
+    while (todo) {                                                                     // uniform
+        const int r = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        unsigned char *dst = x + (row0 + r) * ld_bytes;
+        for (int o = lane * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<u32x4 *>(dst + o) = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+// ---- row maximum (NaN propagates, as torch.max) ---------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void row_max_kernel(const T *__restrict__ x, long long rows, int C, long long ldx, T *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);    // 16 lanes per row
+    float m = -__builtin_inff();
+    if (row < rows) {
+        const T *xr = x + row * ldx;
+        for (int c = sub; c < C; c += 16) {
+            const float v = glue_load<T>(xr + c);
+            m = (v > m || v != v) ? v : m;
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        const float v = __shfl_xor(m, o, 64);
+        m = (v > m || v != v) ? v : m;
+    }
+    if (row < rows && sub == 0) glue_store<T>(out + row, m);
+}
+
+// ---- [B, C, P] -> rows [p0 .. p0 + P) of [B, S, C'] (row stride ld_out): 64 channels x 64 pixels per block through LDS --
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const T *__restrict__ src, const T *__restrict__ add_vec, int C, int P,
+                                                             long long out_image_stride, long long ld_out, T *__restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;                  // 4 rows of 64 per pass
+    const T *s = src + ((size_t)b * C + c0) * (size_t)P + p0;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4)                                         // channel c0 + i, pixel p0 + tx: coalesced along pixels
+        tile[i][tx] = (c0 + i < C && p0 + tx < P) ? glue_load<T>(s + (size_t)i * P + tx) : 0.f;
+    __syncthreads();
+    const float av = (add_vec && c0 + tx < C) ? glue_load<T>(add_vec + c0 + tx) : 0.f;
+    T *o = out + (size_t)b * out_image_stride + (size_t)p0 * ld_out + c0;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4)                                         // pixel p0 + i, channel c0 + tx: coalesced along channels
+        if (p0 + i < P && c0 + tx < C) {
+            glue_store<T>(o + (size_t)i * ld_out + tx, tile[tx][i] + av);    // two stored values, summed in fp32, rounded once (as torch)
+        }
+}
+
 }  // namespace rdetr
 
 using namespace rdetr;
@@ -98,5 +167,54 @@ extern "C" int rdetr_sine_pos_embed(const float *pos, long long rows, int n, int
     else
         hipLaunchKernelGGL((sine_pos_embed_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st, pos, rows, n, F, scale, dt,
                            static_cast<float *>(out));
+    return launch_status();
+}
+
+extern "C" int rdetr_zero_masked_rows(void *x, const unsigned char *mask, long long rows, int row_bytes, long long ld_bytes,
+                                      void *stream)
+{
+    if (rows < 0 || row_bytes <= 0 || ld_bytes < row_bytes) return RDETR_ERR_INVALID_ARG;
+    if ((row_bytes & 15) || (ld_bytes & 15)) return RDETR_ERR_UNSUPPORTED;
+    if (rows == 0) return RDETR_OK;
+    if (!x || !mask || (reinterpret_cast<uintptr_t>(x) & 15)) return RDETR_ERR_INVALID_ARG;
+    const long long nblk = (rows + 255) / 256;
+    if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(zero_masked_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<unsigned char *>(x), mask, rows, row_bytes, ld_bytes);
+    return launch_status();
+}
+
+extern "C" int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long ldx, void *out, void *stream)
+{
+    if (rows < 0 || C <= 0 || ldx < C) return RDETR_ERR_INVALID_ARG;
+    if (rows == 0) return RDETR_OK;
+    if (!x || !out) return RDETR_ERR_INVALID_ARG;
+    const long long nblk = (rows + 15) / 16;
+    if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_bf16)
+        hipLaunchKernelGGL((row_max_kernel<uint16_t>), dim3((unsigned)nblk), dim3(256), 0, st, static_cast<const uint16_t *>(x), rows, C,
+                           ldx, static_cast<uint16_t *>(out));
+    else
+        hipLaunchKernelGGL((row_max_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st, static_cast<const float *>(x), rows, C, ldx,
+                           static_cast<float *>(out));
+    return launch_status();
+}
+
+extern "C" int rdetr_nchw_to_tokens(const void *src, const void *add_vec, int is_bf16, int B, int C, int P,
+                                    long long out_image_stride, long long ld_out, void *out, void *stream)
+{
+    if (B < 0 || C <= 0 || P < 0 || ld_out < C || out_image_stride < 0) return RDETR_ERR_INVALID_ARG;
+    if (B == 0 || P == 0) return RDETR_OK;
+    if (!src || !out) return RDETR_ERR_INVALID_ARG;
+    if (B > 65535 || (C + 63) / 64 > 65535) return RDETR_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((P + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_bf16)
+        hipLaunchKernelGGL((nchw_to_tokens_kernel<uint16_t>), grid, dim3(256), 0, st, static_cast<const uint16_t *>(src),
+                           static_cast<const uint16_t *>(add_vec), C, P, out_image_stride, ld_out, static_cast<uint16_t *>(out));
+    else
+        hipLaunchKernelGGL((nchw_to_tokens_kernel<float>), grid, dim3(256), 0, st, static_cast<const float *>(src),
+                           static_cast<const float *>(add_vec), C, P, out_image_stride, ld_out, static_cast<float *>(out));
     return launch_status();
 }

@@ -99,7 +99,9 @@ class MultiScaleDeformableAttention(nn.Module):
         if key_padding_mask is not None and fill:
             if torch.is_grad_enabled() and v.requires_grad:
                 v = v.masked_fill(key_padding_mask[..., None], float(0))
-            else:                                      # inference: fill the fresh projection in place (no clone pass)
+            elif v.is_cuda and v.dtype in (torch.float32, torch.bfloat16) and v.is_contiguous():
+                ops.zero_masked_rows_(v, key_padding_mask)          # inference: write only the padded rows of the fresh projection
+            else:
                 v.masked_fill_(key_padding_mask[..., None], float(0))
         v = v.view(B, S, H, self.embed_dim // H)
         if merged:

@@ -482,3 +482,77 @@ def sine_pos_embed(pos: torch.Tensor, num_pos_feats: int = 128, temperature: flo
                                           out.data_ptr(), int(dtype == torch.bfloat16), _stream_ptr(pos))
     _lib.check(st, "rdetr_sine_pos_embed")
     return out
+
+
+def _rows_view(x: torch.Tensor, name: str):
+    """(rows, C, row stride in elements) of a tensor whose last dimension is contiguous and whose leading dimensions
+    collapse to evenly strided rows (a contiguous tensor or a column slice of one)."""
+    if x.dim() < 2 or x.stride(-1) != 1:
+        raise _lib.RdetrError(f"{name}: last dimension must be contiguous")
+    C, ld = x.shape[-1], x.stride(-2)
+    rows, expect = 1, ld
+    for d in range(x.dim() - 2, -1, -1):
+        if x.shape[d] != 1 and x.stride(d) != expect:
+            raise _lib.RdetrError(f"{name}: rows must be evenly strided")
+        expect *= x.shape[d]
+        rows *= x.shape[d]
+    return rows, C, ld
+
+
+def zero_masked_rows_(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """In place ``x.masked_fill_(mask[..., None], 0)`` (ms_deform_attn.py:316-319) that writes only the masked rows.
+    x [..., C] fp32|bf16 (rows evenly strided, 16-byte multiples), mask bool/uint8 with one entry per row."""
+    _require_device(x, mask)
+    rows, C, ld = _rows_view(x, "zero_masked_rows_")
+    if mask.numel() != rows:
+        raise _lib.RdetrError("zero_masked_rows_: mask needs one entry per row of x")
+    m = mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+    es = x.element_size()
+    st = _lib.load().rdetr_zero_masked_rows(x.data_ptr(), m.data_ptr(), rows, C * es, ld * es, _stream_ptr(x))
+    _lib.check(st, "rdetr_zero_masked_rows")
+    return x
+
+
+def row_max(x: torch.Tensor) -> torch.Tensor:
+    """``x.max(-1)[0]`` for fp32|bf16 x [..., C] (relation_transformer.py:105); NaN propagates."""
+    _require_device(x)
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.RdetrError("row_max: float32 or bfloat16")
+    rows, C, ld = _rows_view(x, "row_max")
+    out = torch.empty(x.shape[:-1], dtype=x.dtype, device=x.device)
+    st = _lib.load().rdetr_row_max(x.data_ptr(), int(x.dtype == torch.bfloat16), rows, C, ld, out.data_ptr(), _stream_ptr(x))
+    _lib.check(st, "rdetr_row_max")
+    return out
+
+
+def tokens_from_levels(levels, add_vecs=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Level-packed tokens of a feature pyramid: ``cat([x.flatten(2).transpose(1, 2) (+ add_vecs[l]) for x in levels], 1)``
+    (base_transformer.py:17-23; the optional per-channel vectors are the level embeddings, relation_transformer.py:87-89).
+    levels: [B, C, h_l, w_l] fp32|bf16 contiguous; out: optional [B, S, C] destination whose rows may be a column slice of a
+    wider buffer."""
+    x0 = levels[0]
+    _require_device(*levels)
+    B, C = x0.shape[:2]
+    S = sum(x.shape[2] * x.shape[3] for x in levels)
+    if out is None:
+        out = torch.empty(B, S, C, dtype=x0.dtype, device=x0.device)
+    if tuple(out.shape) != (B, S, C) or out.dtype != x0.dtype or out.stride(-1) != 1 or (B > 1 and out.stride(0) < S * out.stride(1)):
+        raise _lib.RdetrError("tokens_from_levels: out must be [B, S, C] in the levels' dtype with contiguous channels")
+    lib, es, row = _lib.load(), out.element_size(), 0
+    for l, x in enumerate(levels):
+        if x.shape[:2] != (B, C) or x.dtype != x0.dtype:
+            raise _lib.RdetrError("tokens_from_levels: levels must agree in batch, channels and dtype")
+        x = x.contiguous()
+        vec = None
+        if add_vecs is not None:
+            vec = add_vecs[l].to(x0.dtype).contiguous()
+            if vec.numel() != C:
+                raise _lib.RdetrError("tokens_from_levels: add_vecs[l] needs C entries")
+        P = x.shape[2] * x.shape[3]
+        st = lib.rdetr_nchw_to_tokens(x.data_ptr(), vec.data_ptr() if vec is not None else None, int(x0.dtype == torch.bfloat16),
+                                      B, C, P, out.stride(0), out.stride(1), out.data_ptr() + row * out.stride(1) * es,
+                                      _stream_ptr(x0))
+        _lib.check(st, "rdetr_nchw_to_tokens")
+        row += P
+    return out

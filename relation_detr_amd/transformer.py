@@ -23,6 +23,7 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
+from . import ops
 from .ms_deform_attn import MultiScaleDeformableAttention
 from .relation import PositionRelationEmbedding
 from .self_attn import RelationSelfAttention
@@ -131,15 +132,20 @@ class RelationTransformerEncoder(nn.Module):
         self.memory_fusion = nn.Sequential(nn.Linear((self.num_layers + 1) * d, d), nn.ReLU(inplace=True), nn.Linear(d, d),
                                            nn.LayerNorm(d))
 
-    def forward(self, query, spatial_shapes, level_start_index, reference_points, query_pos=None, query_key_padding_mask=None):
+    def forward(self, query, spatial_shapes, level_start_index, reference_points, query_pos=None, query_key_padding_mask=None,
+                fusion_buffer=None):
+        """`fusion_buffer`: optional [B, S, 7*d] buffer whose first column block IS `query` (the caller wrote the tokens there)."""
         fuse = self.memory_fusion
         if query.is_cuda and not torch.is_grad_enabled():
             # inference: every layer writes its output straight into its column slice of the fusion input (the
             # reference concatenates the 7 tensors afterwards, relation_transformer.py:212); the slices are then
             # the next layer's input as strided views
             d = self.embed_dim
-            stacked = torch.empty(*query.shape[:-1], (self.num_layers + 1) * d, dtype=query.dtype, device=query.device)
-            stacked[..., :d].copy_(query)
+            if fusion_buffer is not None:
+                stacked = fusion_buffer
+            else:
+                stacked = torch.empty(*query.shape[:-1], (self.num_layers + 1) * d, dtype=query.dtype, device=query.device)
+                stacked[..., :d].copy_(query)
             query = stacked[..., :d]
             for i, layer in enumerate(self.layers):
                 query = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask,
@@ -281,6 +287,10 @@ class RelationTransformer(nn.Module):
         # view is a strided kernel, so pay for one contiguous copy here instead
         return flat.transpose(1, 2).contiguous() if flat.dim() == 3 else flat
 
+    @staticmethod
+    def _fast(t: Tensor) -> bool:
+        return t.is_cuda and not torch.is_grad_enabled() and t.dtype in (torch.float32, torch.bfloat16)
+
     # Everything that depends only on the pyramid's level shapes is built once per (shapes, device) and kept: the shape
     # tables, each pixel's centre / level size / level index and the proposal sizes.  Nothing in `forward` then reads a
     # device tensor back or uploads a host one, so the whole eval forward can be captured in a HIP graph (graph.py).
@@ -335,21 +345,31 @@ class RelationTransformer(nn.Module):
 
     def forward(self, multi_level_feats: Sequence[Tensor], multi_level_masks: Sequence[Tensor],
                 multi_level_pos_embeds: Sequence[Tensor]):
-        feat = self.flatten_levels(multi_level_feats)
         mask = self.flatten_levels(multi_level_masks)
-        pos = self.flatten_levels([p + e.view(1, -1, 1, 1) for p, e in zip(multi_level_pos_embeds, self.level_embeds)])
+        fusion_buffer = None
+        if self._fast(multi_level_feats[0]):
+            # inference: one transposing pass per level straight into the token tensors (csrc/glue.hip) -- the features go into
+            # the first column block of the encoder's memory-fusion input, the level embedding is added on the way
+            d, B = self.embed_dim, multi_level_feats[0].shape[0]
+            fusion_buffer = torch.empty(B, mask.shape[1], (self.encoder.num_layers + 1) * d, dtype=multi_level_feats[0].dtype,
+                                        device=mask.device)
+            feat = ops.tokens_from_levels(multi_level_feats, out=fusion_buffer[..., :d])
+            pos = ops.tokens_from_levels(multi_level_pos_embeds, add_vecs=list(self.level_embeds))
+        else:
+            feat = self.flatten_levels(multi_level_feats)
+            pos = self.flatten_levels([p + e.view(1, -1, 1, 1) for p, e in zip(multi_level_pos_embeds, self.level_embeds)])
         geo, valid_ratios = self.level_misc(multi_level_masks)
         shapes, start = geo["shapes"], geo["start"]
         reference, proposals = self.reference_and_proposals(geo, valid_ratios)
 
         memory = self.encoder(query=feat, query_pos=pos, query_key_padding_mask=mask, spatial_shapes=shapes,
-                              level_start_index=start, reference_points=reference)
+                              level_start_index=start, reference_points=reference, fusion_buffer=fusion_buffer)
 
         out_memory, out_proposals = self.encoder_output(memory, proposals, mask)
         enc_class = self.encoder_class_head(out_memory)
         enc_coord = (self.encoder_bbox_head(out_memory).float() + out_proposals).sigmoid()      # fp32 boxes, no mixed-dtype add
         k = self.two_stage_num_proposals
-        top = torch.topk(enc_class.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
+        top = torch.topk(ops.row_max(enc_class) if self._fast(enc_class) else enc_class.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
         enc_class = enc_class.gather(1, top.expand(-1, -1, self.num_classes))
         enc_coord = enc_coord.gather(1, top.expand(-1, -1, 4))
 

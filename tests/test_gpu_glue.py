@@ -256,3 +256,58 @@ def test_sine_pos_embed_vs_torch(n, F, dtype):
     assert out.shape == expect.shape == (3, 77, n * F)
     tol = 5e-6 if dtype == torch.float32 else 2.0 ** -8
     np.testing.assert_allclose(out.numpy(), expect.numpy(), rtol=0, atol=tol)
+
+
+# ------------------------------------------------------------------------------------------ encoder input / output side
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_zero_masked_rows_matches_masked_fill(dtype):
+    from relation_detr_amd import _lib, ops
+    torch.manual_seed(0)
+    for B, S, C, p in ((2, 1000, 256, 0.3), (1, 77, 256, 1.0), (3, 129, 64, 0.0)):
+        x = torch.randn(B, S, C, device=DEV).to(dtype)
+        mask = torch.rand(B, S, device=DEV) < p
+        want = x.masked_fill(mask[..., None], 0.0)
+        got = ops.zero_masked_rows_(x.clone(), mask)
+        assert torch.equal(got, want)
+    # a column slice of a wider buffer: only the slice's columns of the masked rows are cleared
+    wide = torch.randn(2, 50, 3 * 256, device=DEV).to(dtype)
+    mask = torch.rand(2, 50, device=DEV) < 0.5
+    want = wide.clone()
+    want[..., 256:512] = want[..., 256:512].masked_fill(mask[..., None], 0.0)
+    ops.zero_masked_rows_(wide[..., 256:512], mask)
+    assert torch.equal(wide, want)
+    with pytest.raises(_lib.RdetrError):
+        ops.zero_masked_rows_(torch.randn(4, 8, 256, device=DEV), mask)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_max_matches_torch(dtype):
+    from relation_detr_amd import ops
+    torch.manual_seed(1)
+    for shape in ((4, 2223, 91), (1, 5, 1), (2, 33, 300)):
+        x = torch.randn(*shape, device=DEV).to(dtype)
+        x[0, 1, 0] = float("nan")
+        x[0, 2] = float("-inf")
+        got, want = ops.row_max(x), x.max(-1)[0]
+        assert torch.equal(torch.nan_to_num(got.float(), nan=123.0), torch.nan_to_num(want.float(), nan=123.0))
+    sl = torch.randn(3, 40, 200, device=DEV).to(dtype)[..., 10:101]              # strided rows
+    assert torch.equal(ops.row_max(sl), sl.max(-1)[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tokens_from_levels_matches_flatten_transpose_cat(dtype):
+    from relation_detr_amd import ops
+    torch.manual_seed(2)
+    shapes = [(13, 21), (7, 11), (4, 6), (2, 3)]
+    B, C = 3, 256
+    levels = [torch.randn(B, C, h, w, device=DEV).to(dtype) for h, w in shapes]
+    embeds = torch.randn(len(shapes), C, device=DEV).to(dtype)
+    want = torch.cat([x.flatten(2).transpose(1, 2) for x in levels], 1)
+    assert torch.equal(ops.tokens_from_levels(levels), want)
+    want_e = torch.cat([x.flatten(2).transpose(1, 2) + e.view(1, 1, -1) for x, e in zip(levels, embeds)], 1)
+    assert torch.equal(ops.tokens_from_levels(levels, add_vecs=list(embeds)), want_e)
+    wide = torch.zeros(B, want.shape[1], 7 * C, device=DEV, dtype=dtype)          # into the first column block of a wider buffer
+    out = ops.tokens_from_levels(levels, out=wide[..., :C])
+    assert out.data_ptr() == wide.data_ptr() and torch.equal(wide[..., :C], want) and not wide[..., C:].any()
+    odd = [torch.randn(2, 70, 5, 9, device=DEV).to(dtype)]                        # C and H*W not multiples of the 64 x 64 tile
+    assert torch.equal(ops.tokens_from_levels(odd), odd[0].flatten(2).transpose(1, 2))

@@ -253,6 +253,17 @@ int rdetr_add_layernorm_strided_bf16(const uint16_t *x, const uint16_t *residual
                                      const uint16_t *beta, long long rows, int C, long long ldx, long long ldr,
                                      long long ldo, float eps, uint16_t *out, void *stream);
 
+/* As the strided form, with a second output out2 = out + pos (the next encoder layer's `query + query_pos`,
+ * models/bricks/relation_transformer.py:262): computed from the stored (rounded) `out`, i.e. the bits of a separate add.
+ * pos / out2: rows ldp / ldo2 elements apart, both required. */
+int rdetr_add_layernorm_pos_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                                const float *pos, long long rows, int C, long long ldx, long long ldr, long long ldo,
+                                long long ldp, long long ldo2, float eps, float *out, float *out2, void *stream);
+int rdetr_add_layernorm_pos_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma,
+                                 const uint16_t *beta, const uint16_t *pos, long long rows, int C, long long ldx,
+                                 long long ldr, long long ldo, long long ldp, long long ldo2, float eps, uint16_t *out,
+                                 uint16_t *out2, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused elementwise steps of the decoder's box bookkeeping (each replaces ~8 torch launches on a [B,N,4] tensor).
  *   rdetr_box_refine_f32   out = sigmoid(delta + inverse_sigmoid(ref)),  inverse_sigmoid as util/misc.py:31-35 (eps 1e-3);

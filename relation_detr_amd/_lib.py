@@ -49,6 +49,8 @@ SIGNATURES = {
     "rdetr_add_layernorm_bf16": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
     "rdetr_add_layernorm_strided_f32": [_vp] * 4 + [_c_ll, _c_int, _c_ll, _c_ll, _c_ll, _c_float, _vp, _vp],
     "rdetr_add_layernorm_strided_bf16": [_vp] * 4 + [_c_ll, _c_int, _c_ll, _c_ll, _c_ll, _c_float, _vp, _vp],
+    "rdetr_add_layernorm_pos_f32": [_vp] * 5 + [_c_ll, _c_int] + [_c_ll] * 5 + [_c_float, _vp, _vp, _vp],
+    "rdetr_add_layernorm_pos_bf16": [_vp] * 5 + [_c_ll, _c_int] + [_c_ll] * 5 + [_c_float, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -52,6 +52,10 @@ __device__ __forceinline__ float ln_wave_sum(float v)
     return v;
 }
 
+template <typename T> __device__ __forceinline__ float ln_round(float v);
+template <> __device__ __forceinline__ float ln_round<float>(float v) { return v; }
+template <> __device__ __forceinline__ float ln_round<uint16_t>(float v) { return bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(v)); }
+
 constexpr int kLnWaves = 4;
 constexpr int kLnRowsPerWave = 4;          // C = 256 kernel: half a wave per row (32 lanes x 8 channels), 2 rows per half
 
@@ -104,7 +108,9 @@ __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm256_kernel(const
                                                                            const T *__restrict__ gamma,
                                                                            const T *__restrict__ beta, long long rows,
                                                                            long long ldx, long long ldr, long long ldo,
-                                                                           float eps, T *__restrict__ out)
+                                                                           float eps, T *__restrict__ out,
+                                                                           const T *__restrict__ pos, long long ldp,
+                                                                           T *__restrict__ out2, long long ldo2)
 {
     const int lane = threadIdx.x & 63, half = lane >> 5, c = (lane & 31) * 8;
     const long long row0 = ((long long)blockIdx.x * kLnWaves + (threadIdx.x >> 6)) * kLnRowsPerWave + half;
@@ -152,7 +158,16 @@ __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm256_kernel(const
         float y[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) y[k] = v[i][k] * rstd * g[k] + b[k];
-        if (row < rows) LnIO8<T>::store(out + row * ldo + c, y);
+        if (row < rows) {
+            LnIO8<T>::store(out + row * ldo + c, y);
+            if (out2) {                      // out2 = out + pos, from the STORED (rounded) normalised values: the bits of a separate add
+                float pv[8];
+                LnIO8<T>::load(pos + row * ldp + c, pv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pv[k] += ln_round<T>(y[k]);
+                LnIO8<T>::store(out2 + row * ldo2 + c, pv);
+            }
+        }
     }
 }
 
@@ -161,7 +176,9 @@ __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm_generic_kernel(
                                                                                 const T *__restrict__ gamma,
                                                                                 const T *__restrict__ beta, long long rows,
                                                                                 int C, long long ldx, long long ldr,
-                                                                                long long ldo, float eps, T *__restrict__ out)
+                                                                                long long ldo, float eps, T *__restrict__ out,
+                                                                                const T *__restrict__ pos, long long ldp,
+                                                                                T *__restrict__ out2, long long ldo2)
 {
     const long long row = (long long)blockIdx.x * kLnWaves + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -178,15 +195,19 @@ __global__ __launch_bounds__(kLnWaves *kWave) void add_layernorm_generic_kernel(
     const float rstd = 1.0f / sqrtf(ln_wave_sum(sq) / (float)C + eps);
     for (int c = lane; c < C; c += 64) {
         const float d = LnIO<T>::load1(xr + c) + (rr ? LnIO<T>::load1(rr + c) : 0.f) - mean;
-        LnIO<T>::store1(out + row * ldo + c, d * rstd * LnIO<T>::load1(gamma + c) + LnIO<T>::load1(beta + c));
+        const float y = d * rstd * LnIO<T>::load1(gamma + c) + LnIO<T>::load1(beta + c);
+        LnIO<T>::store1(out + row * ldo + c, y);
+        if (out2) LnIO<T>::store1(out2 + row * ldo2 + c, ln_round<T>(y) + LnIO<T>::load1(pos + row * ldp + c));
     }
 }
 
 template <typename T>
 static int add_layernorm(const T *x, const T *r, const T *gamma, const T *beta, long long rows, int C, long long ldx,
-                         long long ldr, long long ldo, float eps, T *out, hipStream_t stream)
+                         long long ldr, long long ldo, float eps, T *out, hipStream_t stream, const T *pos = nullptr,
+                         long long ldp = 0, T *out2 = nullptr, long long ldo2 = 0)
 {
     if (rows < 0 || C <= 0 || C > 8192 || ldx < C || ldo < C || (r && ldr < C)) return RDETR_ERR_INVALID_ARG;
+    if ((out2 != nullptr) != (pos != nullptr) || (out2 && (ldp < C || ldo2 < C))) return RDETR_ERR_INVALID_ARG;
     if (rows == 0) return RDETR_OK;
     if (!x || !gamma || !beta || !out) return RDETR_ERR_INVALID_ARG;
     const long long nblk = (rows + kLnWaves - 1) / kLnWaves;
@@ -195,12 +216,12 @@ static int add_layernorm(const T *x, const T *r, const T *gamma, const T *beta, 
     auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     const long long a16 = 16 / (long long)sizeof(T);
     if (C == 256 && al16(x) && al16(out) && al16(gamma) && al16(beta) && (!r || al16(r)) && ldx % a16 == 0 && ldo % a16 == 0 &&
-        (!r || ldr % a16 == 0))
+        (!r || ldr % a16 == 0) && (!out2 || (al16(pos) && al16(out2) && ldp % a16 == 0 && ldo2 % a16 == 0)))
         hipLaunchKernelGGL((add_layernorm256_kernel<T>), dim3((unsigned)nblk256), dim3(kLnWaves * kWave), 0, stream, x, r, gamma,
-                           beta, rows, ldx, ldr, ldo, eps, out);
+                           beta, rows, ldx, ldr, ldo, eps, out, pos, ldp, out2, ldo2);
     else
         hipLaunchKernelGGL((add_layernorm_generic_kernel<T>), dim3((unsigned)nblk), dim3(kLnWaves * kWave), 0, stream, x, r,
-                           gamma, beta, rows, C, ldx, ldr, ldo, eps, out);
+                           gamma, beta, rows, C, ldx, ldr, ldo, eps, out, pos, ldp, out2, ldo2);
     return launch_status();
 }
 
@@ -231,4 +252,23 @@ extern "C" int rdetr_add_layernorm_strided_bf16(const uint16_t *x, const uint16_
 {
     return rdetr::add_layernorm<uint16_t>(x, residual, gamma, beta, rows, C, ldx, ldr, ldo, eps, out,
                                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_add_layernorm_pos_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                                           const float *pos, long long rows, int C, long long ldx, long long ldr, long long ldo,
+                                           long long ldp, long long ldo2, float eps, float *out, float *out2, void *stream)
+{
+    if (!pos || !out2) return RDETR_ERR_INVALID_ARG;
+    return rdetr::add_layernorm<float>(x, residual, gamma, beta, rows, C, ldx, ldr, ldo, eps, out, static_cast<hipStream_t>(stream),
+                                       pos, ldp, out2, ldo2);
+}
+
+extern "C" int rdetr_add_layernorm_pos_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *gamma,
+                                            const uint16_t *beta, const uint16_t *pos, long long rows, int C, long long ldx,
+                                            long long ldr, long long ldo, long long ldp, long long ldo2, float eps, uint16_t *out,
+                                            uint16_t *out2, void *stream)
+{
+    if (!pos || !out2) return RDETR_ERR_INVALID_ARG;
+    return rdetr::add_layernorm<uint16_t>(x, residual, gamma, beta, rows, C, ldx, ldr, ldo, eps, out,
+                                          static_cast<hipStream_t>(stream), pos, ldp, out2, ldo2);
 }

@@ -386,9 +386,11 @@ def _row_matrix(t: torch.Tensor):
 
 
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
-                   eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   eps: float = 1e-5, out: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None):
     """LayerNorm(x + residual) over the last dimension in one pass (fp32 / bf16; residual may be None).  `x`,
     `residual` and `out` may be column slices of wider row-major tensors (evenly strided rows).
+    With ``pos`` (x's shape and dtype) returns ``(out, out + pos)`` -- the second tensor is what the next encoder layer
+    feeds its attention as ``query + query_pos``, produced by the same pass.
     Inference-only (no autograd): the harness uses it under torch.no_grad()."""
     _require_device(x, residual, weight, bias, out)
     if x.dtype not in (torch.float32, torch.bfloat16):
@@ -411,6 +413,17 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: to
         raise _lib.RdetrError("add_layer_norm: out must have evenly strided rows with a contiguous last dimension")
     w, b = weight.detach().to(x.dtype).contiguous(), bias.detach().to(x.dtype).contiguous()
     lib = _lib.load()
+    if pos is not None:
+        _require_device(pos)
+        if pos.shape != x.shape or pos.dtype != x.dtype:
+            raise _lib.RdetrError("add_layer_norm: pos must have x's shape and dtype")
+        pos, ldp = _row_matrix(pos)
+        out2 = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        fp = lib.rdetr_add_layernorm_pos_f32 if x.dtype == torch.float32 else lib.rdetr_add_layernorm_pos_bf16
+        st = fp(x.data_ptr(), None if residual is None else residual.data_ptr(), w.data_ptr(), b.data_ptr(), pos.data_ptr(),
+                x.numel() // C, C, ldx, ldr, ldo, ldp, C, float(eps), out.data_ptr(), out2.data_ptr(), _stream_ptr(x))
+        _lib.check(st, "rdetr_add_layernorm_pos")
+        return out, out2
     fn = lib.rdetr_add_layernorm_strided_f32 if x.dtype == torch.float32 else lib.rdetr_add_layernorm_strided_bf16
     st = fn(x.data_ptr(), None if residual is None else residual.data_ptr(), w.data_ptr(), b.data_ptr(),
             x.numel() // C, C, ldx, ldr, ldo, float(eps), out.data_ptr(), _stream_ptr(x))

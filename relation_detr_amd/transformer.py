@@ -17,6 +17,7 @@ time the same glue with the CPU oracle's operators as the host baseline; the def
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Sequence
 
 import torch
@@ -111,13 +112,21 @@ class RelationTransformerEncoderLayer(nn.Module):
         nn.init.xavier_uniform_(self.linear1.weight)
         nn.init.xavier_uniform_(self.linear2.weight)
 
-    def forward(self, query, query_pos, reference_points, spatial_shapes, level_start_index, key_padding_mask=None, out=None):
-        """`out`: optional destination of the layer's output (a column slice of the encoder's memory-fusion input)."""
-        attn = self.self_attn(query=query if query_pos is None else query + query_pos, reference_points=reference_points,
+    def forward(self, query, query_pos, reference_points, spatial_shapes, level_start_index, key_padding_mask=None, out=None,
+                query_plus_pos=None, next_pos=None):
+        """`out`: optional destination of the layer's output (a column slice of the encoder's memory-fusion input).
+        `query_plus_pos`: `query + query_pos` if the caller already has it; `next_pos`: also return output + next_pos
+        (the next layer's `query_plus_pos`), produced by the final add+LayerNorm pass -> (output, output + next_pos)."""
+        if query_plus_pos is None:
+            query_plus_pos = query if query_pos is None else query + query_pos
+        attn = self.self_attn(query=query_plus_pos, reference_points=reference_points,
                               value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               key_padding_mask=key_padding_mask)
         query = add_norm(self.norm1, query, attn)
-        return add_norm(self.norm2, query, self.linear2(linear_relu(self.linear1, query)), out=out)
+        ffn = self.linear2(linear_relu(self.linear1, query))
+        if next_pos is not None:
+            return ops.add_layer_norm(query, ffn, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, pos=next_pos)
+        return add_norm(self.norm2, query, ffn, out=out)
 
 
 class RelationTransformerEncoder(nn.Module):
@@ -147,9 +156,15 @@ class RelationTransformerEncoder(nn.Module):
                 stacked = torch.empty(*query.shape[:-1], (self.num_layers + 1) * d, dtype=query.dtype, device=query.device)
                 stacked[..., :d].copy_(query)
             query = stacked[..., :d]
+            fuse_pos = (query_pos is not None and query.dtype in (torch.float32, torch.bfloat16)
+                        and os.environ.get("RDETR_LN_POS", "1") != "0")          # =0: separate add (A/B)
+            qpp = None
             for i, layer in enumerate(self.layers):
-                query = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask,
-                              out=stacked[..., (i + 1) * d:(i + 2) * d])
+                last = i + 1 == self.num_layers
+                res = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask,
+                            out=stacked[..., (i + 1) * d:(i + 2) * d], query_plus_pos=qpp,
+                            next_pos=query_pos if fuse_pos and not last else None)
+                query, qpp = res if isinstance(res, tuple) else (res, None)
             return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], stacked)))
         outs = [query]
         for layer in self.layers:

@@ -311,3 +311,19 @@ def test_tokens_from_levels_matches_flatten_transpose_cat(dtype):
     assert out.data_ptr() == wide.data_ptr() and torch.equal(wide[..., :C], want) and not wide[..., C:].any()
     odd = [torch.randn(2, 70, 5, 9, device=DEV).to(dtype)]                        # C and H*W not multiples of the 64 x 64 tile
     assert torch.equal(ops.tokens_from_levels(odd), odd[0].flatten(2).transpose(1, 2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [256, 96])
+def test_add_layer_norm_second_output_is_the_separate_add(dtype, C):
+    """out2 = out + pos from the same pass carries the bits of `out + pos` computed afterwards."""
+    from relation_detr_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(3, 301, C, device=DEV).to(dtype)
+    r = torch.randn_like(x)
+    pos = torch.randn_like(x)
+    w, b = torch.randn(C, device=DEV).to(dtype), torch.randn(C, device=DEV).to(dtype)
+    want = ops.add_layer_norm(x, r, w, b, 1e-5)
+    wide = torch.zeros(3, 301, 3 * C, device=DEV, dtype=dtype)
+    out, out2 = ops.add_layer_norm(x, r, w, b, 1e-5, out=wide[..., C:2 * C], pos=pos)
+    assert torch.equal(out, want) and torch.equal(out2, want + pos) and out2.is_contiguous()

@@ -95,7 +95,13 @@ class MultiScaleDeformableAttention(nn.Module):
         B, Nq, _ = query.shape
         S = value.shape[1]
         H, L, P = self.num_heads, self.num_levels, self.num_points
-        v = self.value_proj(value)
+        if value.dim() == 3 and not value.is_contiguous() and value.stride(2) == 1 and value.stride(0) == S * value.stride(1):
+            # a column slice of a wider row-major buffer: as a 2-d strided matrix the projection stays ONE GEMM with the bias
+            # in its epilogue (on a non-contiguous 3-d input nn.Linear runs matmul + a separate bias pass)
+            v = torch.nn.functional.linear(value.view(B * S, value.shape[2]), self.value_proj.weight,
+                                           self.value_proj.bias).view(B, S, -1)
+        else:
+            v = self.value_proj(value)
         if key_padding_mask is not None and fill:
             if torch.is_grad_enabled() and v.requires_grad:
                 v = v.masked_fill(key_padding_mask[..., None], float(0))

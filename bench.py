@@ -274,6 +274,7 @@ def main():
                 return select_detections(classes[-1].float(), coords[-1].float(), t[3 * L0])
 
             L0 = len(feats)
+            forward300 = ImageGroups(forward300, nstreams, device=dev)
             run300 = forward300
             if launch == "hipGraph replay":
                 from relation_detr_amd.graph import GraphedCall

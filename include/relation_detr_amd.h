@@ -297,6 +297,16 @@ int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long l
 int rdetr_nchw_to_tokens(const void *src, const void *add_vec, int is_bf16, int B, int C, int P,
                          long long out_image_stride, long long ld_out, void *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense projection with K = 256 (embed_dim) for tall bf16 inputs, hand-written MFMA kernel (csrc/linear.hip):
+ *   out[M, N] = act(x[M, 256] w[N, 256]^T + bias[N]),  bf16 storage, fp32 accumulation, one rounding.
+ * Replaces the library GEMM behind nn.Linear for MSDA's value_proj / output_proj / merged sampling_offsets + attention_weights
+ * projection (models/bricks/ms_deform_attn.py:259-262) and the FFN's linear1 + ReLU (models/bricks/relation_transformer.py:226-233).
+ *   x: rows ldx elements apart (>= 256), w: [N, 256] contiguous (nn.Linear.weight), bias: [N] or NULL, out: rows ldo apart;
+ *   N a multiple of 32, ldx / ldo multiples of 8, bases 16-byte aligned (else RDETR_ERR_UNSUPPORTED); relu: 0 | 1. */
+int rdetr_linear_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias, long long M, int N,
+                           int relu, uint16_t *out, long long ldo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,173 @@
+// Dense projection with K = 256 (the model's embed_dim) for bf16 activations on gfx950:  out = act(X W^T + b).
+//
+// Replaces the library GEMM behind the path's K = 256 nn.Linear layers -- MSDA value_proj / output_proj / the merged
+// sampling_offsets + attention_weights projection (models/bricks/ms_deform_attn.py:259-262) and the FFN's linear1 + ReLU
+// (models/bricks/relation_transformer.py:226-233) -- for tall inputs (tens of thousands of rows).  With K this short the
+// library kernels spend their time in tile prologues / epilogues (200-570 TFLOP/s, 2.3 TB/s of output for the FFN); the
+// shape is really a streaming problem: read X once, write out once, and the whole weight slice fits in LDS.
+//
+//   workgroup   512 threads = 8 waves, persistent over row tiles; owns a slice of NT * 16 <= 256 output columns whose weights
+//               (<= 128 KiB bf16) sit in LDS for the whole kernel, in MFMA-fragment order (every A-operand read is one
+//               contiguous, conflict-free ds_read_b128 per lane)
+//   wave        32 rows per step: X^T is the B operand straight from global memory (a lane's 8 consecutive k = 16 contiguous
+//               bytes of its row; the next step's rows are prefetched into a second register set), the TRANSPOSED product
+//               out^T = W X^T leaves lane (row, g) with 4 consecutive output columns per 16 x 16 tile; the slice's columns are
+//               permuted over the tiles so that two tiles give 8 consecutive columns = one 16-byte bf16 store
+//   math        v_mfma_f32_16x16x32_bf16, fp32 accumulators initialised with the bias, one rounding to bf16 at the end
+// Bound: HBM (X in + out; the weights come from L2 once per workgroup).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace rdetr {
+
+typedef __bf16 ln_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kLinK = 256;
+constexpr int kLinThreads = 512;           // 8 waves = 2 per SIMD: one wave's LDS reads / packing overlap the other's MFMAs
+constexpr int kLinRows = 32;               // rows per wave step
+
+template <int NT, bool RELU>
+__global__ __launch_bounds__(kLinThreads) void linear_k256_kernel(const uint16_t *__restrict__ x, long long ldx,
+                                                                  const uint16_t *__restrict__ w, const uint16_t *__restrict__ bias,
+                                                                  long long M, int N, uint16_t *__restrict__ out, long long ldo, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lin_lds[];
+    u32x4 *wl = reinterpret_cast<u32x4 *>(lin_lds);                           // [NT][8 k-steps][64 lanes] 16-byte fragments
+    float *bl = reinterpret_cast<float *>(lin_lds + NT * 8 * 64 * 16);        // [NT * 16] bias, natural column order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * (NT * 16);                                    // first column of this workgroup's slice
+
+    // column of the slice carried by row m of tile t:  32 (t >> 1) + 8 (m >> 2) + 4 (t & 1) + (m & 3)
+    {
+        // weights -> LDS: rows are read whole (32 lanes x 16 B = one 512-byte row, coalesced) and scattered into fragment order:
+        // piece p of slice column c goes to fragment (tile t, k-step p >> 2, lane 16 (p & 3) + m)
+        constexpr int kPer = NT * 16 * 32 / kLinThreads;                      // 16-byte pieces per thread (16 / 12), all in flight
+        u32x4 piece[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int idx = i * kLinThreads + tid, c = idx >> 5, p = idx & 31;
+            piece[i] = n0 + c < N ? *reinterpret_cast<const u32x4 *>(w + (size_t)(n0 + c) * kLinK + 8 * p) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int idx = i * kLinThreads + tid, c = idx >> 5, p = idx & 31;
+            const int t = 2 * (c >> 5) + ((c >> 2) & 1), m = 4 * ((c >> 3) & 3) + (c & 3);
+            wl[(t * 8 + (p >> 2)) * 64 + 16 * (p & 3) + m] = piece[i];
+        }
+    }
+    for (int i = tid; i < NT * 16; i += kLinThreads) bl[i] = (bias && n0 + i < N) ? bf16_bits_to_f32(bias[n0 + i]) : 0.f;
+    __syncthreads();
+
+    const long long nsteps = (M + kLinRows - 1) / kLinRows;
+    constexpr int kWaves = kLinThreads / 64;
+    const long long stride = (long long)gridDim.x * kWaves;
+    long long step = (long long)blockIdx.x * kWaves + wave;
+
+    u32x4 xc[2][8], xn[2][8];
+    auto load_rows = [&](long long st, u32x4 (&dst)[2][8]) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const long long row = st * kLinRows + cb * 16 + col;
+            const uint16_t *p = x + row * ldx + 8 * g;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                dst[cb][s] = (st < nsteps && row < M) ? *reinterpret_cast<const u32x4 *>(p + 32 * s) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    load_rows(step, xc);
+    for (; step < nsteps; step += stride) {
+        load_rows(step + stride, xn);                                         // prefetch (all zeros past the end)
+        const long long row_a = step * kLinRows + col, row_b = row_a + 16;
+        uint16_t *oa = out + row_a * ldo + n0 + 8 * g, *ob = out + row_b * ldo + n0 + 8 * g;
+        // two tiles (= 8 consecutive output columns per lane) at a time: 4 independent accumulator chains, stored as soon as they
+        // are complete, so that only 16 accumulator registers are live and two waves fit a SIMD
+#pragma unroll
+        for (int u = 0; u < NT / 2; ++u) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 32 * u + 8 * g + 4 * e);
+                acc[e][0] = b4;
+                acc[e][1] = b4;
+            }
+            if (!(dbg & 2))
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const ln_bf16x8 a = __builtin_bit_cast(ln_bf16x8, wl[((2 * u + e) * 8 + s) * 64 + lane]);
+                    acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[0][s]), acc[e][0], 0, 0, 0);
+                    acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[1][s]), acc[e][1], 0, 0, 0);
+                }
+            }
+            if (n0 + 32 * u + 8 * g < N) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    f32x4 lo = acc[0][cb], hi = acc[1][cb];
+                    if (RELU) {
+                        lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+                        hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+                    }
+                    u32x4 pk;
+                    pk.x = f32_to_bf16_bits(lo.x) | (f32_to_bf16_bits(lo.y) << 16);
+                    pk.y = f32_to_bf16_bits(lo.z) | (f32_to_bf16_bits(lo.w) << 16);
+                    pk.z = f32_to_bf16_bits(hi.x) | (f32_to_bf16_bits(hi.y) << 16);
+                    pk.w = f32_to_bf16_bits(hi.z) | (f32_to_bf16_bits(hi.w) << 16);
+                    if ((cb ? row_b : row_a) < M && !((dbg & 1) && pk.x != 0x12345u)) *reinterpret_cast<u32x4 *>((cb ? ob : oa) + 32 * u) = pk;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                                // keep the next pair's LDS reads from piling up here
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) xc[cb][s] = xn[cb][s];
+    }
+}
+
+template <int NT, bool RELU>
+static int linear_launch(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias, long long M, int N,
+                         uint16_t *out, long long ldo, int chunks, hipStream_t st)
+{
+    auto kern = linear_k256_kernel<NT, RELU>;
+    constexpr int lds = NT * 8 * 64 * 16 + NT * 16 * 4;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return RDETR_ERR_LAUNCH;
+    const long long steps = (M + kLinRows - 1) / kLinRows;
+    long long gx = (steps + kLinThreads / 64 - 1) / (kLinThreads / 64);
+    const long long cap = 256 / chunks > 0 ? 256 / chunks : 1;                // about one resident workgroup per CU
+    if (gx > cap) gx = cap;
+    static const int dbg = []() { const char *e = getenv("RDETR_LINEAR_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(kLinThreads), (size_t)lds, st, x, ldx, w, bias, M, N, out,
+                       ldo, dbg);
+    return launch_status();
+}
+
+}  // namespace rdetr
+
+using namespace rdetr;
+
+// out[M, N] = act(x[M, 256] w[N, 256]^T + bias[N]); bf16 storage, fp32 accumulation.  N a multiple of 32; x / out rows ldx / ldo
+// elements apart (multiples of 8, 16-byte aligned bases); bias nullable; relu: 0 | 1.
+extern "C" int rdetr_linear_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias, long long M,
+                                      int N, int relu, uint16_t *out, long long ldo, void *stream)
+{
+    if (M < 0 || N <= 0 || ldx < kLinK || ldo < N) return RDETR_ERR_INVALID_ARG;
+    if ((N & 31) || (ldx & 7) || (ldo & 7)) return RDETR_ERR_UNSUPPORTED;
+    if (M == 0) return RDETR_OK;
+    if (!x || !w || !out) return RDETR_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15) return RDETR_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // slices of 256 columns (16 tiles), or of 192 when that divides N and 256 does not (N = 384)
+    if (N % 256 == 0 || N < 192 || (N % 192 != 0)) {
+        const int chunks = (N + 255) / 256;
+        return relu ? linear_launch<16, true>(x, ldx, w, bias, M, N, out, ldo, chunks, st)
+                    : linear_launch<16, false>(x, ldx, w, bias, M, N, out, ldo, chunks, st);
+    }
+    const int chunks = N / 192;
+    return relu ? linear_launch<12, true>(x, ldx, w, bias, M, N, out, ldo, chunks, st)
+                : linear_launch<12, false>(x, ldx, w, bias, M, N, out, ldo, chunks, st);
+}

@@ -569,3 +569,39 @@ def tokens_from_levels(levels, add_vecs=None, out: Optional[torch.Tensor] = None
         _lib.check(st, "rdetr_nchw_to_tokens")
         row += P
     return out
+
+
+def linear_k256_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """True where `linear_k256` applies: bf16 device tensors, K = 256, N a multiple of 32, evenly strided 16-byte aligned rows."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] == 256
+            and weight.dim() == 2 and weight.shape[1] == 256 and weight.shape[0] % 32 == 0 and weight.is_contiguous()):
+        return False
+    try:
+        _, _, ld = _rows_view(x, "linear_k256")
+    except _lib.RdetrError:
+        return False
+    return ld % 8 == 0 and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
+
+
+def linear_k256(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``relu?(F.linear(x, weight, bias))`` for bf16 x [..., 256] (rows may be a column slice of a wider buffer) and
+    weight [N, 256], N % 32 == 0, through the hand-written MFMA kernel (csrc/linear.hip).  Inference only."""
+    _require_device(x, weight, bias, out)
+    if not linear_k256_supported(x, weight):
+        raise _lib.RdetrError("linear_k256: needs bf16, K = 256, N % 32 == 0, evenly strided 16-byte aligned rows")
+    rows, _, ldx = _rows_view(x, "linear_k256")
+    N = weight.shape[0]
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.numel() != N):
+        raise _lib.RdetrError("linear_k256: bias must be bf16 [N]")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (*x.shape[:-1], N) or out.dtype != x.dtype:
+        raise _lib.RdetrError("linear_k256: out must be [..., N] bf16")
+    orows, _, ldo = _rows_view(out, "linear_k256")
+    if orows != rows or ldo % 8 or out.data_ptr() % 16:
+        raise _lib.RdetrError("linear_k256: out rows must be 16-byte aligned")
+    st = _lib.load().rdetr_linear_k256_bf16(x.data_ptr(), ldx, weight.data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
+                                            rows, N, int(relu), out.data_ptr(), ldo, _stream_ptr(x))
+    _lib.check(st, "rdetr_linear_k256_bf16")
+    return out

@@ -73,10 +73,20 @@ def add_norm(norm: nn.LayerNorm, x: Tensor, residual: Tensor = None, out: Tensor
     return y
 
 
+_K256_MIN_ROWS = 16384          # below this the library GEMM's shorter fixed cost wins (csrc/linear.hip)
+
+
 def linear_relu(linear: nn.Linear, x: Tensor) -> Tensor:
     """relu(linear(x)); on a device the ReLU runs in the GEMM's epilogue (hipBLASLt) instead of a pass of its own over
     the [.., d_ffn] activations."""
     if x.is_cuda and linear.bias is not None and not (torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)):
+        rows = x.numel() // x.shape[-1]
+        if (rows >= _K256_MIN_ROWS and linear.out_features >= 1024 and os.environ.get("RDETR_LINEAR_K256", "0") == "1"
+                and not torch.is_grad_enabled() and ops.linear_k256_supported(x, linear.weight)):
+            # opt-in: hand-written MFMA kernel for the tall K = 256, wide-output linear1 of the encoder FFN.  Alone it beats the
+            # library GEMM (72 vs 87 us at 44,646 rows), inside the two-group replay it does not (-1 %: its persistent
+            # 128-KiB-LDS workgroups leave the other group's kernels no room), hence not the default (DESIGN.md 4.12)
+            return ops.linear_k256(x, linear.weight, linear.bias, relu=True)
         y = torch._addmm_activation(linear.bias, x.reshape(-1, x.shape[-1]), linear.weight.t(), use_gelu=False)
         return y.view(*x.shape[:-1], linear.out_features)
     return F.relu(linear(x))

@@ -327,3 +327,37 @@ def test_add_layer_norm_second_output_is_the_separate_add(dtype, C):
     wide = torch.zeros(3, 301, 3 * C, device=DEV, dtype=dtype)
     out, out2 = ops.add_layer_norm(x, r, w, b, 1e-5, out=wide[..., C:2 * C], pos=pos)
     assert torch.equal(out, want) and torch.equal(out2, want + pos) and out2.is_contiguous()
+
+
+# ------------------------------------------------------------------------------------------ K = 256 projection (MFMA)
+@pytest.mark.parametrize("N,relu", [(256, False), (384, False), (2048, True), (512, False), (64, True), (96, False)])
+def test_linear_k256_matches_fp32_reference(N, relu):
+    """out = act(x W^T + b): against the fp32 product of the bf16-rounded operands, one bf16 rounding of tolerance."""
+    from relation_detr_amd import _lib, ops
+    torch.manual_seed(6)
+    for M in (4 * 22323 // 2, 37, 1):
+        x = torch.randn(M, 256, device=DEV).bfloat16()
+        w = (torch.randn(N, 256, device=DEV) * 0.06).bfloat16()
+        b = torch.randn(N, device=DEV).bfloat16()
+        want = x.float() @ w.float().t() + b.float()
+        if relu:
+            want = want.relu()
+        got = ops.linear_k256(x, w, b, relu=relu)
+        assert got.shape == (M, N) and got.dtype == torch.bfloat16
+        err = (got.float() - want).abs()
+        assert float((err - want.abs() * 2 ** -8).max()) <= 2e-3, float(err.max())     # one bf16 ulp + accumulation order
+        nb = ops.linear_k256(x, w, None, relu=relu)
+        want_nb = x.float() @ w.float().t()
+        assert float(((nb.float() - (want_nb.relu() if relu else want_nb)).abs() - want_nb.abs() * 2 ** -8).max()) <= 2e-3
+    # strided input rows (a column slice), 3-d input, strided output
+    wide = torch.randn(2, 301, 3 * 256, device=DEV).bfloat16()
+    w = (torch.randn(N, 256, device=DEV) * 0.06).bfloat16()
+    b = torch.randn(N, device=DEV).bfloat16()
+    got = ops.linear_k256(wide[..., 256:512], w, b, relu=relu)
+    want = wide[..., 256:512].float() @ w.float().t() + b.float()
+    want = want.relu() if relu else want
+    assert got.shape == (2, 301, N) and float(((got.float() - want).abs() - want.abs() * 2 ** -8).max()) <= 2e-3
+    with pytest.raises(_lib.RdetrError):
+        ops.linear_k256(torch.randn(8, 128, device=DEV).bfloat16(), w)
+    with pytest.raises(_lib.RdetrError):
+        ops.linear_k256(torch.randn(8, 256, device=DEV).bfloat16(), torch.randn(91, 256, device=DEV).bfloat16())

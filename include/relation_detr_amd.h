@@ -307,6 +307,17 @@ int rdetr_nchw_to_tokens(const void *src, const void *add_vec, int is_bf16, int 
 int rdetr_linear_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias, long long M, int N,
                            int relu, uint16_t *out, long long ldo, void *stream);
 
+/* Fused feed-forward block (csrc/ffn.hip): out[M, 256] = relu(x[M, 256] w1[F, 256]^T + b1[F]) w2[256, F]^T + b2[256], i.e.
+ * linear2(relu(linear1(x))) of the encoder / decoder layers (models/bricks/relation_transformer.py:226-233, 272-275) without the
+ * [M, F] activations ever reaching HBM.  bf16 storage, fp32 accumulation, the hidden activations rounded to bf16 where the unfused
+ * path stores them.  The two weight matrices (as nn.Linear keeps them, contiguous) are first re-ordered ONCE per weight update
+ * into the order the kernel streams them: rdetr_ffn_k256_pack_bf16 fills `packed` (2 * 256 * F bf16 elements, 16-byte aligned).
+ * x / out rows ldx / ldo elements apart (multiples of 8, 16-byte aligned bases); F a multiple of 64, <= 4096 (else
+ * RDETR_ERR_UNSUPPORTED). */
+int rdetr_ffn_k256_pack_bf16(const uint16_t *w1, const uint16_t *w2, int F, uint16_t *packed, void *stream);
+int rdetr_ffn_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1, const uint16_t *b2,
+                        long long M, int F, uint16_t *out, long long ldo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -605,3 +605,54 @@ def linear_k256(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
                                             rows, N, int(relu), out.data_ptr(), ldo, _stream_ptr(x))
     _lib.check(st, "rdetr_linear_k256_bf16")
     return out
+
+
+def ffn_k256_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+    F = w1.shape[0] if w1.dim() == 2 else 0
+    return (linear_k256_supported(x, w1) and w2.dtype == torch.bfloat16 and tuple(w2.shape) == (256, F) and F % 64 == 0
+            and F <= 4096 and w2.is_contiguous() and w2.data_ptr() % 16 == 0)
+
+
+_FFN_PACKED = {}        # (w1 ptr, w2 ptr) -> (versions, packed): the fragment-order copy of a layer's two weight matrices
+
+
+def ffn_k256_packed_weights(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """The (w1, w2) pair re-ordered for `ffn_k256` (rdetr_ffn_k256_pack_bf16); cached until either tensor changes."""
+    key = (w1.data_ptr(), w2.data_ptr(), w1.device)
+    ver = (w1._version, w2._version, tuple(w1.shape))
+    hit = _FFN_PACKED.get(key)
+    if hit is None or hit[0] != ver:
+        F = w1.shape[0]
+        packed = torch.empty(2 * 256 * F, dtype=torch.bfloat16, device=w1.device)
+        st = _lib.load().rdetr_ffn_k256_pack_bf16(w1.data_ptr(), w2.data_ptr(), F, packed.data_ptr(), _stream_ptr(w1))
+        _lib.check(st, "rdetr_ffn_k256_pack_bf16")
+        if len(_FFN_PACKED) > 64:
+            _FFN_PACKED.clear()
+        hit = (ver, packed)
+        _FFN_PACKED[key] = hit
+    return hit[1]
+
+
+def ffn_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear(F.relu(F.linear(x, w1, b1)), w2, b2)`` for bf16 x [..., 256], w1 [F, 256], w2 [256, F] in one kernel: the
+    [.., F] activations stay in registers (csrc/ffn.hip; relation_transformer.py:226-233, 272-275).  Inference only."""
+    _require_device(x, w1, b1, w2, b2, out)
+    if not ffn_k256_supported(x, w1, w2):
+        raise _lib.RdetrError("ffn_k256: needs bf16, embed_dim 256, d_ffn % 64 == 0 (<= 4096), evenly strided 16-byte aligned rows")
+    F = w1.shape[0]
+    if b1.dtype != torch.bfloat16 or b2.dtype != torch.bfloat16 or b1.numel() != F or b2.numel() != 256:
+        raise _lib.RdetrError("ffn_k256: biases must be bf16 [F] and [256]")
+    rows, _, ldx = _rows_view(x, "ffn_k256")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], 256, dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != tuple(x.shape) or out.dtype != x.dtype:
+        raise _lib.RdetrError("ffn_k256: out must have x's shape and dtype")
+    orows, _, ldo = _rows_view(out, "ffn_k256")
+    if orows != rows or ldo % 8 or out.data_ptr() % 16:
+        raise _lib.RdetrError("ffn_k256: out rows must be 16-byte aligned")
+    packed = ffn_k256_packed_weights(w1, w2)
+    st = _lib.load().rdetr_ffn_k256_bf16(x.data_ptr(), ldx, packed.data_ptr(), b1.contiguous().data_ptr(),
+                                         b2.contiguous().data_ptr(), rows, F, out.data_ptr(), ldo, _stream_ptr(x))
+    _lib.check(st, "rdetr_ffn_k256_bf16")
+    return out

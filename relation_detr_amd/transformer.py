@@ -92,6 +92,16 @@ def linear_relu(linear: nn.Linear, x: Tensor) -> Tensor:
     return F.relu(linear(x))
 
 
+def feed_forward(linear1: nn.Linear, linear2: nn.Linear, x: Tensor) -> Tensor:
+    """linear2(relu(linear1(x))) (relation_transformer.py:226-233, 272-275).  Tall bf16 inputs at inference go through the fused
+    kernel (csrc/ffn.hip: the [rows, d_ffn] activations never reach HBM); RDETR_FFN_FUSED=0 keeps the two library GEMMs."""
+    if (x.is_cuda and not torch.is_grad_enabled() and x.numel() // x.shape[-1] >= _K256_MIN_ROWS
+            and linear1.bias is not None and linear2.bias is not None and os.environ.get("RDETR_FFN_FUSED", "1") != "0"
+            and ops.ffn_k256_supported(x, linear1.weight, linear2.weight)):
+        return ops.ffn_k256(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias)
+    return linear2(linear_relu(linear1, x))
+
+
 class MLP(nn.Module):
     """models/bricks/basic.py:6-24 (ReLU between layers, none after the last)."""
 
@@ -133,7 +143,7 @@ class RelationTransformerEncoderLayer(nn.Module):
                               value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               key_padding_mask=key_padding_mask)
         query = add_norm(self.norm1, query, attn)
-        ffn = self.linear2(linear_relu(self.linear1, query))
+        ffn = feed_forward(self.linear1, self.linear2, query)
         if next_pos is not None:
             return ops.add_layer_norm(query, ffn, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, pos=next_pos)
         return add_norm(self.norm2, query, ffn, out=out)
@@ -207,7 +217,7 @@ class RelationTransformerDecoderLayer(nn.Module):
                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                 key_padding_mask=key_padding_mask)
         query = add_norm(self.norm1, query, cross)
-        return add_norm(self.norm3, query, self.linear2(linear_relu(self.linear1, query)))
+        return add_norm(self.norm3, query, feed_forward(self.linear1, self.linear2, query))
 
 
 class RelationTransformerDecoder(nn.Module):

@@ -361,3 +361,36 @@ def test_linear_k256_matches_fp32_reference(N, relu):
         ops.linear_k256(torch.randn(8, 128, device=DEV).bfloat16(), w)
     with pytest.raises(_lib.RdetrError):
         ops.linear_k256(torch.randn(8, 256, device=DEV).bfloat16(), torch.randn(91, 256, device=DEV).bfloat16())
+
+
+@pytest.mark.parametrize("F", [2048, 128, 1024])
+def test_ffn_k256_matches_unfused_reference(F):
+    """linear2(relu(linear1(x))) in one kernel: against fp32 products of the bf16 operands with the hidden activations rounded
+    to bf16 (where the unfused bf16 path stores them)."""
+    from relation_detr_amd import _lib, ops
+    torch.manual_seed(7)
+    w1 = (torch.randn(F, 256, device=DEV) * 0.06).bfloat16()
+    b1 = (torch.randn(F, device=DEV) * 0.5).bfloat16()
+    w2 = (torch.randn(256, F, device=DEV) * (1.0 / F ** 0.5)).bfloat16()
+    b2 = torch.randn(256, device=DEV).bfloat16()
+
+    def reference(x):
+        h = (x.float() @ w1.float().t() + b1.float()).relu().bfloat16().float()
+        return h @ w2.float().t() + b2.float()
+
+    for M in (2 * 22323, 300, 1, 257):
+        x = torch.randn(M, 256, device=DEV).bfloat16()
+        got, want = ops.ffn_k256(x, w1, b1, w2, b2), reference(x)
+        assert got.shape == (M, 256) and got.dtype == torch.bfloat16
+        err = (got.float() - want).abs()
+        # one bf16 rounding of the result + a few flipped roundings of hidden units (accumulation order) seen through w2
+        assert float((err - want.abs() * 2 ** -8).max()) <= 1.5e-2, float(err.max())
+        assert float(err.mean()) <= 3e-3
+    wide = torch.randn(2, 129, 3 * 256, device=DEV).bfloat16()
+    out = torch.zeros(2, 129, 2 * 256, device=DEV, dtype=torch.bfloat16)
+    got = ops.ffn_k256(wide[..., 512:], w1, b1, w2, b2, out=out[..., :256])
+    want = reference(wide[..., 512:].reshape(-1, 256)).view(2, 129, 256)
+    assert got.data_ptr() == out.data_ptr() and not out[..., 256:].any()
+    assert float(((got.float() - want).abs() - want.abs() * 2 ** -8).max()) <= 1.5e-2
+    with pytest.raises(_lib.RdetrError):
+        ops.ffn_k256(torch.randn(4, 256, device=DEV).bfloat16(), w1[:96], b1[:96], w2[:, :96].contiguous(), b2)

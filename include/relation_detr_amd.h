@@ -317,6 +317,12 @@ int rdetr_linear_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *w, 
 int rdetr_ffn_k256_pack_bf16(const uint16_t *w1, const uint16_t *w2, int F, uint16_t *packed, void *stream);
 int rdetr_ffn_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1, const uint16_t *b2,
                         long long M, int F, uint16_t *out, long long ldo, void *stream);
+/* The same block with the layer's closing residual + LayerNorm in its epilogue: out = LayerNorm(x + ffn(x)) with gamma / beta [256]
+ * bf16 and eps (relation_transformer.py:272-276; ffn(x) rounded to bf16 first, as the unfused path stores it; fp32 two-pass
+ * statistics).  pos / out2 (both or neither, rows ldp / ldo2 apart): out2 = out + pos, the next layer's query + query_pos. */
+int rdetr_ffn_ln_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1, const uint16_t *b2,
+                           const uint16_t *gamma, const uint16_t *beta, float eps, const uint16_t *pos, long long ldp,
+                           long long M, int F, uint16_t *out, long long ldo, uint16_t *out2, long long ldo2, void *stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rdetr_linear_k256_bf16": [_vp, _c_ll, _vp, _vp, _c_ll, _c_int, _c_int, _vp, _c_ll, _vp],
     "rdetr_ffn_k256_pack_bf16": [_vp, _vp, _c_int, _vp, _vp],
     "rdetr_ffn_k256_bf16": [_vp, _c_ll, _vp, _vp, _vp, _c_ll, _c_int, _vp, _c_ll, _vp],
+    "rdetr_ffn_ln_k256_bf16": [_vp, _c_ll, _vp, _vp, _vp, _vp, _vp, _c_float, _vp, _c_ll, _c_ll, _c_int, _vp, _c_ll, _vp, _c_ll, _vp],
     "rdetr_nchw_to_tokens": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _vp, _vp],
     "rdetr_add_layernorm_f32": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],
     "rdetr_add_layernorm_bf16": [_vp] * 4 + [_c_ll, _c_int, _c_float, _vp, _vp],

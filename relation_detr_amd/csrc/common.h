@@ -37,6 +37,19 @@ __device__ __forceinline__ unsigned int f32_to_bf16_bits(float f)
     return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)f);
 }
 
+// Two f32 -> one register of two bf16 (a in the low half), round-to-nearest-even: ONE v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_bf16x2(float a, float b)
+{
+    return __builtin_bit_cast(unsigned int, bf16x2_t{(__bf16)a, (__bf16)b});
+}
+// max(x, 0) on both bf16 halves: a negative bf16 is a negative int16 (v_pk_max_i16); -0 -> +0, NaN with the sign bit -> 0
+__device__ __forceinline__ unsigned int relu_bf16x2(unsigned int packed)
+{
+    return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, packed), s16x2_t{0, 0}));
+}
+
 inline int launch_status()
 {
     return hipGetLastError() == hipSuccess ? RDETR_OK : RDETR_ERR_LAUNCH;

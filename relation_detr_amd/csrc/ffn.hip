@@ -34,10 +34,14 @@ constexpr int kFfnBufBytes = kFfnW1Bytes + kFfnW2Bytes;
 // slot of a 16-wide tile sequence that carries index i (i = 32 u + 8 g + 4 e + r  <->  tile 2u + e, row 4g + r)
 __device__ __forceinline__ int ffn_index(int tile, int m) { return 32 * (tile >> 1) + 8 * (m >> 2) + 4 * (tile & 1) + (m & 3); }
 
+template <bool LN>
 __global__ __launch_bounds__(kFfnThreads) void ffn_k256_kernel(const uint16_t *__restrict__ x, long long ldx,
                                                                const uint16_t *__restrict__ packed, const uint16_t *__restrict__ b1,
                                                                const uint16_t *__restrict__ b2,
-                                                               long long M, int F, uint16_t *__restrict__ out, long long ldo, int dbg)
+                                                               long long M, int F, uint16_t *__restrict__ out, long long ldo, int dbg,
+                                                               const uint16_t *__restrict__ gamma, const uint16_t *__restrict__ beta,
+                                                               float eps, const uint16_t *__restrict__ pos, long long ldp,
+                                                               uint16_t *__restrict__ out2, long long ldo2)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ffn_lds[];
     float *b1l = reinterpret_cast<float *>(ffn_lds + 2 * kFfnBufBytes);      // [F]
@@ -46,6 +50,11 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_k256_kernel(const uint16_t *_
     const int col = lane & 15, g = lane >> 4;
     for (int i = tid; i < F; i += kFfnThreads) b1l[i] = bf16_bits_to_f32(b1[i]);
     if (tid < kFfnK) b2l[tid] = bf16_bits_to_f32(b2[tid]);
+    float *gml = b2l + kFfnK, *btl = gml + kFfnK;                             // LayerNorm weight / bias (gamma != nullptr)
+    if (LN && tid < kFfnK) {
+        gml[tid] = bf16_bits_to_f32(gamma[tid]);
+        btl[tid] = bf16_bits_to_f32(beta[tid]);
+    }
 
     // LDS-DMA of chunk c into buffer c & 1: the chunk's 64 fragments of 1 KiB are one contiguous 64-KiB slab of the PACKED
     // weights (ffn_pack_kernel below), 8 instructions per wave, each a fully coalesced 1-KiB read
@@ -87,58 +96,132 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_k256_kernel(const uint16_t *_
             if (c + 1 < nchunks && !(dbg & 1)) issue_chunk(c + 1);
             const u32x4 *w1l = reinterpret_cast<const u32x4 *>(ffn_lds + (c & 1) * kFfnBufBytes);
             const u32x4 *w2l = reinterpret_cast<const u32x4 *>(ffn_lds + (c & 1) * kFfnBufBytes + kFfnW1Bytes);
+            // two tile pairs (32 hidden units each) per chunk, software-pipelined: GEMM 1 of pair 1 is interleaved with GEMM 2 of
+            // pair 0, so that the matrix pipe has independent work while a pair's activations are packed
+            auto gemm1_step = [&](int u, int s, f32x4 (&acc1)[2][2]) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {                                     // tile pair = 32 hidden units
-                f32x4 acc1[2][2];
+                for (int e = 0; e < 2; ++e) {
+                    const ffn_bf16x8 a = __builtin_bit_cast(ffn_bf16x8, w1l[((2 * u + e) * 8 + s) * 64 + lane]);
+                    acc1[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, xr[0][s]), acc1[e][0], 0, 0, 0);
+                    acc1[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, xr[1][s]), acc1[e][1], 0, 0, 0);
+                }
+            };
+            auto gemm2_step = [&](int u, int ot, const u32x4 (&h)[2]) {
+                const ffn_bf16x8 a = __builtin_bit_cast(ffn_bf16x8, w2l[(ot * 2 + u) * 64 + lane]);
+                acc2[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, h[0]), acc2[ot][0], 0, 0, 0);
+                acc2[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, h[1]), acc2[ot][1], 0, 0, 0);
+            };
+            auto init1 = [&](int u, f32x4 (&acc1)[2][2]) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b1l + c * kFfnHC + 32 * u + 8 * g + 4 * e);
                     acc1[e][0] = b4;
                     acc1[e][1] = b4;
                 }
-                if (!(dbg & 8))
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const ffn_bf16x8 a = __builtin_bit_cast(ffn_bf16x8, w1l[((2 * u + e) * 8 + s) * 64 + lane]);
-                        acc1[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, xr[0][s]), acc1[e][0], 0, 0, 0);
-                        acc1[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, xr[1][s]), acc1[e][1], 0, 0, 0);
-                    }
-                }
-                u32x4 h[2];                                                   // relu, round to bf16: B operand of GEMM 2, k = 8 g + j
+            };
+            auto activate = [&](const f32x4 (&acc1)[2][2], u32x4 (&h)[2]) {   // relu, round to bf16: B operand of GEMM 2, k = 8 g + j
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     const f32x4 lo = acc1[0][cb], hi = acc1[1][cb];
-                    h[cb].x = f32_to_bf16_bits(fmaxf(lo.x, 0.f)) | (f32_to_bf16_bits(fmaxf(lo.y, 0.f)) << 16);
-                    h[cb].y = f32_to_bf16_bits(fmaxf(lo.z, 0.f)) | (f32_to_bf16_bits(fmaxf(lo.w, 0.f)) << 16);
-                    h[cb].z = f32_to_bf16_bits(fmaxf(hi.x, 0.f)) | (f32_to_bf16_bits(fmaxf(hi.y, 0.f)) << 16);
-                    h[cb].w = f32_to_bf16_bits(fmaxf(hi.z, 0.f)) | (f32_to_bf16_bits(fmaxf(hi.w, 0.f)) << 16);
+                    h[cb].x = relu_bf16x2(pack_bf16x2(lo.x, lo.y));          // round, then relu on the packed pair: 2 instructions
+                    h[cb].y = relu_bf16x2(pack_bf16x2(lo.z, lo.w));
+                    h[cb].z = relu_bf16x2(pack_bf16x2(hi.x, hi.y));
+                    h[cb].w = relu_bf16x2(pack_bf16x2(hi.z, hi.w));
                 }
-                if (!(dbg & 4))
+            };
+            f32x4 acc1a[2][2], acc1b[2][2];
+            u32x4 h0[2], h1[2];
+            init1(0, acc1a);
+            if (!(dbg & 8))
 #pragma unroll
-                for (int ot = 0; ot < 16; ++ot) {
-                    const ffn_bf16x8 a = __builtin_bit_cast(ffn_bf16x8, w2l[(ot * 2 + u) * 64 + lane]);
-                    acc2[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, h[0]), acc2[ot][0], 0, 0, 0);
-                    acc2[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, h[1]), acc2[ot][1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < 8; ++s) gemm1_step(0, s, acc1a);
+            activate(acc1a, h0);
+            init1(1, acc1b);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (!(dbg & 8)) gemm1_step(1, s, acc1b);
+                if (!(dbg & 4)) { gemm2_step(0, 2 * s, h0); gemm2_step(0, 2 * s + 1, h0); }
             }
+            activate(acc1b, h1);
+            if (!(dbg & 4))
+#pragma unroll
+                for (int ot = 0; ot < 16; ++ot) gemm2_step(1, ot, h1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // the epilogue's row pointers (out, pos, out2) are derived from values the compiler cannot see before this point: hoisted
+        // above the chunk loop they would occupy 12 registers there and spill the loop
+        unsigned col_e = (unsigned)col;
+        asm volatile("" : "+v"(col_e));
+        const long long row_e = (tile * kFfnWaves + wave) * kFfnRows + col_e;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            const long long row = cb ? row_b : row_a;
+            const long long row = row_e + 16 * cb;
+            if constexpr (LN) {
+                // out = LayerNorm(x + ffn(x)) (relation_transformer.py:272-276): the residual is the X^T fragment of k-step u
+                // (x[row][32 u + 8 g ..] -- the very columns this lane holds of tile pair u); the row is spread over the 4 lanes
+                // l, l ^ 16, l ^ 32, l ^ 48.  ffn(x) is rounded to bf16 first, as the unfused path stores it; fp32 two-pass statistics
+                float sum = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const u32x4 r = xr[cb][u];
+                    f32x4 &lo = acc2[2 * u][cb], &hi = acc2[2 * u + 1][cb];
+                    lo.x = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(lo.x)) + __builtin_bit_cast(float, r.x << 16);
+                    lo.y = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(lo.y)) + __builtin_bit_cast(float, r.x & 0xffff0000u);
+                    lo.z = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(lo.z)) + __builtin_bit_cast(float, r.y << 16);
+                    lo.w = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(lo.w)) + __builtin_bit_cast(float, r.y & 0xffff0000u);
+                    hi.x = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(hi.x)) + __builtin_bit_cast(float, r.z << 16);
+                    hi.y = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(hi.y)) + __builtin_bit_cast(float, r.z & 0xffff0000u);
+                    hi.z = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(hi.z)) + __builtin_bit_cast(float, r.w << 16);
+                    hi.w = bf16_bits_to_f32((uint16_t)f32_to_bf16_bits(hi.w)) + __builtin_bit_cast(float, r.w & 0xffff0000u);
+                    sum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.0f / kFfnK);
+                float sq = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    f32x4 &lo = acc2[2 * u][cb], &hi = acc2[2 * u + 1][cb];
+                    lo.x -= mean; lo.y -= mean; lo.z -= mean; lo.w -= mean;
+                    hi.x -= mean; hi.y -= mean; hi.z -= mean; hi.w -= mean;
+                    sq += ((lo.x * lo.x + lo.y * lo.y) + (lo.z * lo.z + lo.w * lo.w)) + ((hi.x * hi.x + hi.y * hi.y) + (hi.z * hi.z + hi.w * hi.w));
+                }
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / kFfnK) + eps);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    f32x4 &lo = acc2[2 * u][cb], &hi = acc2[2 * u + 1][cb];
+                    const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gml + 32 * u + 8 * g), g1 = *reinterpret_cast<const f32x4 *>(gml + 32 * u + 8 * g + 4);
+                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(btl + 32 * u + 8 * g), c1 = *reinterpret_cast<const f32x4 *>(btl + 32 * u + 8 * g + 4);
+                    lo.x = lo.x * rstd * g0.x + c0.x; lo.y = lo.y * rstd * g0.y + c0.y; lo.z = lo.z * rstd * g0.z + c0.z; lo.w = lo.w * rstd * g0.w + c0.w;
+                    hi.x = hi.x * rstd * g1.x + c1.x; hi.y = hi.y * rstd * g1.y + c1.y; hi.z = hi.z * rstd * g1.z + c1.z; hi.w = hi.w * rstd * g1.w + c1.w;
+                }
+            }
             if (row < M) {
                 uint16_t *o = out + row * ldo + 8 * g;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const f32x4 lo = acc2[2 * u][cb], hi = acc2[2 * u + 1][cb];
                     u32x4 pk;
-                    pk.x = f32_to_bf16_bits(lo.x) | (f32_to_bf16_bits(lo.y) << 16);
-                    pk.y = f32_to_bf16_bits(lo.z) | (f32_to_bf16_bits(lo.w) << 16);
-                    pk.z = f32_to_bf16_bits(hi.x) | (f32_to_bf16_bits(hi.y) << 16);
-                    pk.w = f32_to_bf16_bits(hi.z) | (f32_to_bf16_bits(hi.w) << 16);
+                    pk.x = pack_bf16x2(lo.x, lo.y);
+                    pk.y = pack_bf16x2(lo.z, lo.w);
+                    pk.z = pack_bf16x2(hi.x, hi.y);
+                    pk.w = pack_bf16x2(hi.z, hi.w);
                     *reinterpret_cast<u32x4 *>(o + 32 * u) = pk;
+                    if (LN && out2) {            // out2 = out + pos from the STORED values: the next layer's query + query_pos
+                        const u32x4 pv = *reinterpret_cast<const u32x4 *>(pos + row * ldp + 8 * g + 32 * u);
+                        u32x4 q;
+                        q.x = f32_to_bf16_bits(__builtin_bit_cast(float, pk.x << 16) + __builtin_bit_cast(float, pv.x << 16)) |
+                              (f32_to_bf16_bits(__builtin_bit_cast(float, pk.x & 0xffff0000u) + __builtin_bit_cast(float, pv.x & 0xffff0000u)) << 16);
+                        q.y = f32_to_bf16_bits(__builtin_bit_cast(float, pk.y << 16) + __builtin_bit_cast(float, pv.y << 16)) |
+                              (f32_to_bf16_bits(__builtin_bit_cast(float, pk.y & 0xffff0000u) + __builtin_bit_cast(float, pv.y & 0xffff0000u)) << 16);
+                        q.z = f32_to_bf16_bits(__builtin_bit_cast(float, pk.z << 16) + __builtin_bit_cast(float, pv.z << 16)) |
+                              (f32_to_bf16_bits(__builtin_bit_cast(float, pk.z & 0xffff0000u) + __builtin_bit_cast(float, pv.z & 0xffff0000u)) << 16);
+                        q.w = f32_to_bf16_bits(__builtin_bit_cast(float, pk.w << 16) + __builtin_bit_cast(float, pv.w << 16)) |
+                              (f32_to_bf16_bits(__builtin_bit_cast(float, pk.w & 0xffff0000u) + __builtin_bit_cast(float, pv.w & 0xffff0000u)) << 16);
+                        *reinterpret_cast<u32x4 *>(out2 + row * ldo2 + 8 * g + 32 * u) = q;
+                    }
                 }
             }
         }
@@ -180,8 +263,9 @@ extern "C" int rdetr_ffn_k256_pack_bf16(const uint16_t *w1, const uint16_t *w2, 
 
 // out[M, 256] = relu(x[M, 256] w1[F, 256]^T + b1[F]) w2[256, F]^T + b2[256] with (w1, w2) packed by rdetr_ffn_k256_pack_bf16; bf16
 // storage, fp32 accumulation, the hidden activations rounded to bf16 (as the unfused path stores them).  F % 64 == 0, <= 4096.
-extern "C" int rdetr_ffn_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1, const uint16_t *b2,
-                                   long long M, int F, uint16_t *out, long long ldo, void *stream)
+static int ffn_launch(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1, const uint16_t *b2, long long M,
+                      int F, uint16_t *out, long long ldo, const uint16_t *gamma, const uint16_t *beta, float eps, const uint16_t *pos,
+                      long long ldp, uint16_t *out2, long long ldo2, void *stream)
 {
     if (M < 0 || F <= 0 || ldx < kFfnK || ldo < kFfnK) return RDETR_ERR_INVALID_ARG;
     if ((F % kFfnHC) || F > 4096 || (ldx & 7) || (ldo & 7)) return RDETR_ERR_UNSUPPORTED;
@@ -189,14 +273,40 @@ extern "C" int rdetr_ffn_k256_bf16(const uint16_t *x, long long ldx, const uint1
     if (!x || !packed || !b1 || !b2 || !out) return RDETR_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15)
         return RDETR_ERR_UNSUPPORTED;
-    const int lds = 2 * kFfnBufBytes + (F + kFfnK) * 4;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_k256_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFfnBufBytes + (4096 + kFfnK) * 4);
-    if (attr != hipSuccess) return RDETR_ERR_LAUNCH;
+    const int lds = 2 * kFfnBufBytes + (F + 3 * kFfnK) * 4;
+    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_k256_kernel<false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFfnBufBytes + (4096 + 3 * kFfnK) * 4);
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_k256_kernel<true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFfnBufBytes + (4096 + 3 * kFfnK) * 4);
+    if (attr0 != hipSuccess || attr1 != hipSuccess) return RDETR_ERR_LAUNCH;
     const long long ntiles = (M + kFfnWaves * kFfnRows - 1) / (kFfnWaves * kFfnRows);
     const long long gx = ntiles < 256 ? ntiles : 256;
     static const int dbg = []() { const char *e = getenv("RDETR_FFN_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
-    hipLaunchKernelGGL(ffn_k256_kernel, dim3((unsigned)gx), dim3(kFfnThreads), (size_t)lds, static_cast<hipStream_t>(stream), x, ldx,
-                       packed, b1, b2, M, F, out, ldo, dbg);
+    if (gamma)
+        hipLaunchKernelGGL(ffn_k256_kernel<true>, dim3((unsigned)gx), dim3(kFfnThreads), (size_t)lds, static_cast<hipStream_t>(stream), x,
+                           ldx, packed, b1, b2, M, F, out, ldo, dbg, gamma, beta, eps, pos, ldp, out2, ldo2);
+    else
+        hipLaunchKernelGGL(ffn_k256_kernel<false>, dim3((unsigned)gx), dim3(kFfnThreads), (size_t)lds, static_cast<hipStream_t>(stream), x,
+                           ldx, packed, b1, b2, M, F, out, ldo, dbg, gamma, beta, eps, pos, ldp, out2, ldo2);
     return launch_status();
+}
+
+extern "C" int rdetr_ffn_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1, const uint16_t *b2,
+                                   long long M, int F, uint16_t *out, long long ldo, void *stream)
+{
+    return ffn_launch(x, ldx, packed, b1, b2, M, F, out, ldo, nullptr, nullptr, 0.f, nullptr, 0, nullptr, 0, stream);
+}
+
+// out = LayerNorm(x + ffn(x)) (gamma, beta [256], eps) from the same kernel -- the end of an encoder / decoder layer
+// (relation_transformer.py:272-276); with pos / out2 (both or neither): out2 = out + pos, the next layer's query + query_pos.
+extern "C" int rdetr_ffn_ln_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1,
+                                      const uint16_t *b2, const uint16_t *gamma, const uint16_t *beta, float eps,
+                                      const uint16_t *pos, long long ldp, long long M, int F, uint16_t *out, long long ldo,
+                                      uint16_t *out2, long long ldo2, void *stream)
+{
+    if (!gamma || !beta || (pos != nullptr) != (out2 != nullptr)) return RDETR_ERR_INVALID_ARG;
+    if (pos && (ldp < kFfnK || ldo2 < kFfnK)) return RDETR_ERR_INVALID_ARG;
+    if (pos && ((ldp & 7) || (ldo2 & 7) || ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(out2)) & 15)))
+        return RDETR_ERR_UNSUPPORTED;
+    return ffn_launch(x, ldx, packed, b1, b2, M, F, out, ldo, gamma, beta, eps, pos, ldp, out2, ldo2, stream);
 }

@@ -656,3 +656,39 @@ def ffn_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tens
                                          b2.contiguous().data_ptr(), rows, F, out.data_ptr(), ldo, _stream_ptr(x))
     _lib.check(st, "rdetr_ffn_k256_bf16")
     return out
+
+
+def ffn_ln_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, gamma: torch.Tensor,
+                beta: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None):
+    """``LayerNorm(x + linear2(relu(linear1(x))))`` in one kernel (the end of an encoder / decoder layer,
+    relation_transformer.py:272-276); with ``pos`` returns ``(out, out + pos)``.  bf16, inference only; see `ffn_k256`."""
+    _require_device(x, w1, b1, w2, b2, gamma, beta, out, pos)
+    if not ffn_k256_supported(x, w1, w2):
+        raise _lib.RdetrError("ffn_ln_k256: needs bf16, embed_dim 256, d_ffn % 64 == 0 (<= 4096), evenly strided 16-byte aligned rows")
+    F = w1.shape[0]
+    for t, n in ((b1, F), (b2, 256), (gamma, 256), (beta, 256)):
+        if t.dtype != torch.bfloat16 or t.numel() != n:
+            raise _lib.RdetrError("ffn_ln_k256: biases / LayerNorm parameters must be bf16 of the matching size")
+    rows, _, ldx = _rows_view(x, "ffn_ln_k256")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], 256, dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != tuple(x.shape) or out.dtype != x.dtype:
+        raise _lib.RdetrError("ffn_ln_k256: out must have x's shape and dtype")
+    orows, _, ldo = _rows_view(out, "ffn_ln_k256")
+    if orows != rows or ldo % 8 or out.data_ptr() % 16:
+        raise _lib.RdetrError("ffn_ln_k256: out rows must be 16-byte aligned")
+    out2, ldp = None, 0
+    if pos is not None:
+        if tuple(pos.shape) != tuple(x.shape) or pos.dtype != x.dtype:
+            raise _lib.RdetrError("ffn_ln_k256: pos must have x's shape and dtype")
+        prows, _, ldp = _rows_view(pos, "ffn_ln_k256")
+        if ldp % 8 or pos.data_ptr() % 16:
+            raise _lib.RdetrError("ffn_ln_k256: pos rows must be 16-byte aligned")
+        out2 = torch.empty(*x.shape[:-1], 256, dtype=x.dtype, device=x.device)
+    packed = ffn_k256_packed_weights(w1, w2)
+    st = _lib.load().rdetr_ffn_ln_k256_bf16(x.data_ptr(), ldx, packed.data_ptr(), b1.contiguous().data_ptr(), b2.contiguous().data_ptr(),
+                                            gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(), float(eps),
+                                            None if pos is None else pos.data_ptr(), ldp, rows, F, out.data_ptr(), ldo,
+                                            None if out2 is None else out2.data_ptr(), 256, _stream_ptr(x))
+    _lib.check(st, "rdetr_ffn_ln_k256_bf16")
+    return out if pos is None else (out, out2)

@@ -92,12 +92,16 @@ def linear_relu(linear: nn.Linear, x: Tensor) -> Tensor:
     return F.relu(linear(x))
 
 
+def _fused_ffn_applies(linear1: nn.Linear, linear2: nn.Linear, x: Tensor) -> bool:
+    return (x.is_cuda and not torch.is_grad_enabled() and x.numel() // x.shape[-1] >= _K256_MIN_ROWS
+            and linear1.bias is not None and linear2.bias is not None and os.environ.get("RDETR_FFN_FUSED", "1") != "0"
+            and ops.ffn_k256_supported(x, linear1.weight, linear2.weight))
+
+
 def feed_forward(linear1: nn.Linear, linear2: nn.Linear, x: Tensor) -> Tensor:
     """linear2(relu(linear1(x))) (relation_transformer.py:226-233, 272-275).  Tall bf16 inputs at inference go through the fused
     kernel (csrc/ffn.hip: the [rows, d_ffn] activations never reach HBM); RDETR_FFN_FUSED=0 keeps the two library GEMMs."""
-    if (x.is_cuda and not torch.is_grad_enabled() and x.numel() // x.shape[-1] >= _K256_MIN_ROWS
-            and linear1.bias is not None and linear2.bias is not None and os.environ.get("RDETR_FFN_FUSED", "1") != "0"
-            and ops.ffn_k256_supported(x, linear1.weight, linear2.weight)):
+    if _fused_ffn_applies(linear1, linear2, x):
         return ops.ffn_k256(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias)
     return linear2(linear_relu(linear1, x))
 
@@ -143,6 +147,12 @@ class RelationTransformerEncoderLayer(nn.Module):
                               value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               key_padding_mask=key_padding_mask)
         query = add_norm(self.norm1, query, attn)
+        if _fused_ffn_applies(self.linear1, self.linear2, query) and os.environ.get("RDETR_FFN_LN", "0") == "1":
+            # opt-in: feed-forward block, residual, LayerNorm (and the next layer's query + pos) in ONE kernel (csrc/ffn.hip).
+            # Correct (tests/test_gpu_glue.py) but 1 % slower than fused FFN + the add+LayerNorm kernel: the epilogue's
+            # registers make the compiler spill inside the MFMA loop
+            return ops.ffn_ln_k256(query, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                   self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, pos=next_pos)
         ffn = feed_forward(self.linear1, self.linear2, query)
         if next_pos is not None:
             return ops.add_layer_norm(query, ffn, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, pos=next_pos)

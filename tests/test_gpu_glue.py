@@ -394,3 +394,25 @@ def test_ffn_k256_matches_unfused_reference(F):
     assert float(((got.float() - want).abs() - want.abs() * 2 ** -8).max()) <= 1.5e-2
     with pytest.raises(_lib.RdetrError):
         ops.ffn_k256(torch.randn(4, 256, device=DEV).bfloat16(), w1[:96], b1[:96], w2[:, :96].contiguous(), b2)
+
+
+def test_ffn_ln_k256_is_ffn_then_add_layer_norm():
+    """The LayerNorm epilogue reproduces ops.ffn_k256 followed by ops.add_layer_norm (+ pos) bit for bit."""
+    from relation_detr_amd import ops
+    torch.manual_seed(8)
+    F = 2048
+    w1 = (torch.randn(F, 256, device=DEV) * 0.06).bfloat16()
+    b1 = (torch.randn(F, device=DEV) * 0.5).bfloat16()
+    w2 = (torch.randn(256, F, device=DEV) * (1.0 / F ** 0.5)).bfloat16()
+    b2 = torch.randn(256, device=DEV).bfloat16()
+    gamma, beta = torch.randn(256, device=DEV).bfloat16(), torch.randn(256, device=DEV).bfloat16()
+    for shape in ((2, 22323, 256), (1, 37, 256)):
+        x = torch.randn(*shape, device=DEV).bfloat16()
+        pos = torch.randn(*shape, device=DEV).bfloat16()
+        want = ops.add_layer_norm(x, ops.ffn_k256(x, w1, b1, w2, b2), gamma, beta, 1e-5)
+        got = ops.ffn_ln_k256(x, w1, b1, w2, b2, gamma, beta, 1e-5)
+        assert float((got.float() - want.float()).abs().max()) <= 2 ** -6           # fp32 summation order of the statistics
+        assert float((got.float() - want.float()).abs().mean()) <= 1e-4
+        wide = torch.zeros(*shape[:2], 3 * 256, device=DEV, dtype=torch.bfloat16)
+        o, o2 = ops.ffn_ln_k256(x, w1, b1, w2, b2, gamma, beta, 1e-5, out=wide[..., 256:512], pos=pos)
+        assert torch.equal(o, got) and torch.equal(o2, got + pos) and not wide[..., :256].any() and not wide[..., 512:].any()

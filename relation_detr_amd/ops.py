@@ -626,6 +626,9 @@ def ffn_k256_packed_weights(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
         packed = torch.empty(2 * 256 * F, dtype=torch.bfloat16, device=w1.device)
         st = _lib.load().rdetr_ffn_k256_pack_bf16(w1.data_ptr(), w2.data_ptr(), F, packed.data_ptr(), _stream_ptr(w1))
         _lib.check(st, "rdetr_ffn_k256_pack_bf16")
+        if not torch.cuda.is_current_stream_capturing():
+            # once per weight update: other streams (image groups) pick the cached tensor up without an event of their own
+            torch.cuda.current_stream(w1.device).synchronize()
         if len(_FFN_PACKED) > 64:
             _FFN_PACKED.clear()
         hit = (ver, packed)

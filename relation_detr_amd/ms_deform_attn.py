@@ -86,6 +86,8 @@ class MultiScaleDeformableAttention(nn.Module):
         if cache is None or cache[0] != key:
             with torch.no_grad():
                 cache = (key, torch.cat([so.weight, aw.weight], 0).contiguous(), torch.cat([so.bias, aw.bias], 0).contiguous())
+            if so.weight.is_cuda and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(so.weight.device).synchronize()      # other streams (image groups) use it without an event
             object.__setattr__(self, "_merged_cache", cache)
         return cache[1], cache[2]
 

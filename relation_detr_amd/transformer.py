@@ -360,6 +360,8 @@ class RelationTransformer(nn.Module):
                        proposal_wh=torch.cat(prop))
             if len(cls._geometry_cache) > 16:
                 cls._geometry_cache.clear()
+            if torch.device(device).type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(device).synchronize()       # built once; other streams (image groups) read it
             cls._geometry_cache[key] = geo
         return geo
 

@@ -307,6 +307,17 @@ int rdetr_nchw_to_tokens(const void *src, const void *add_vec, int is_bf16, int 
 int rdetr_linear_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias, long long M, int N,
                            int relu, uint16_t *out, long long ldo, void *stream);
 
+/* MSDA's output_proj with the encoder layer's residual + LayerNorm in its epilogue (csrc/linear.hip):
+ *   out[M, 256] = LayerNorm(residual + (x[M, 256] w[256, 256]^T + bias))     (models/bricks/ms_deform_attn.py:372-376 followed by
+ *   norm1(query + attn), relation_transformer.py:262-271); the projection is rounded to bf16 before the residual is added, as the
+ *   unfused path stores it; fp32 two-pass statistics.  The weight is re-ordered once per weight update by
+ *   rdetr_linear_pack_k256_bf16 (`packed`: 65,536 bf16 elements).  Rows ldx / ldr / ldo elements apart (multiples of 8), bases
+ *   16-byte aligned; bias nullable; gamma / beta [256] bf16. */
+int rdetr_linear_pack_k256_bf16(const uint16_t *w, uint16_t *packed, void *stream);
+int rdetr_linear_ln_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *bias,
+                              const uint16_t *residual, long long ldr, const uint16_t *gamma, const uint16_t *beta, float eps,
+                              long long M, uint16_t *out, long long ldo, void *stream);
+
 /* Fused feed-forward block (csrc/ffn.hip): out[M, 256] = relu(x[M, 256] w1[F, 256]^T + b1[F]) w2[256, F]^T + b2[256], i.e.
  * linear2(relu(linear1(x))) of the encoder / decoder layers (models/bricks/relation_transformer.py:226-233, 272-275) without the
  * [M, F] activations ever reaching HBM.  bf16 storage, fp32 accumulation, the hidden activations rounded to bf16 where the unfused

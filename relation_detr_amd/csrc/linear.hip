@@ -146,6 +146,134 @@ static int linear_launch(const uint16_t *x, long long ldx, const uint16_t *w, co
     return launch_status();
 }
 
+
+// ---- N = 256 projection with the layer's residual + LayerNorm in the epilogue ------------------------------------------------
+// out = LayerNorm(residual + (X W^T + b)): MSDA's output_proj followed by norm1(query + attn) of the encoder layer
+// (models/bricks/ms_deform_attn.py:372-376 + relation_transformer.py:262-271).  A row's 256 outputs sit in the 4 lanes
+// (row, g = 0..3), 64 values each, so the statistics cost two xor-shuffles.  The weights come PACKED in fragment order
+// (linear_pack_kernel) and are brought to LDS by 128 coalesced 1-KiB LDS-DMA instructions.
+constexpr int kLnlThreads = 512;
+constexpr int kLnlWaves = kLnlThreads / 64;
+
+__global__ __launch_bounds__(256) void linear_pack_kernel(const uint16_t *__restrict__ w, u32x4 *__restrict__ packed)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;                           // [16 tiles][8 k-steps][64 lanes] 16-byte pieces
+    if (idx >= 16 * 8 * 64) return;
+    const int t = idx >> 9, s = (idx >> 6) & 7, l = idx & 63, m = l & 15, kb = l >> 4;
+    const int n = 32 * (t >> 1) + 8 * (m >> 2) + 4 * (t & 1) + (m & 3);
+    packed[idx] = *reinterpret_cast<const u32x4 *>(w + (size_t)n * kLinK + 32 * s + 8 * kb);
+}
+
+__global__ __launch_bounds__(kLnlThreads) void linear_ln_k256_kernel(const uint16_t *__restrict__ x, long long ldx,
+                                                                     const uint16_t *__restrict__ packed,
+                                                                     const uint16_t *__restrict__ bias,
+                                                                     const uint16_t *__restrict__ res, long long ldr,
+                                                                     const uint16_t *__restrict__ gamma,
+                                                                     const uint16_t *__restrict__ beta, float eps, long long M,
+                                                                     uint16_t *__restrict__ out, long long ldo)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lin_lds[];
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(lin_lds);               // 128 KiB of fragments
+    float *bl = reinterpret_cast<float *>(lin_lds + 16 * 8 * 64 * 16);        // bias | gamma | beta, 256 each
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    {
+        const unsigned lane_off = (unsigned)lane * 16u;
+#pragma unroll 1
+        for (int i = 0; i < 128 / kLnlWaves; ++i) {
+            const int f = wave * (128 / kLnlWaves) + i;                       // uniform
+            const unsigned m0v = (unsigned)f * 1024u;
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(packed) + f * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(lane_off), "s"(src) : "memory", "m0");
+        }
+    }
+    if (tid < 256) {
+        bl[tid] = bias ? bf16_bits_to_f32(bias[tid]) : 0.f;
+        bl[256 + tid] = bf16_bits_to_f32(gamma[tid]);
+        bl[512 + tid] = bf16_bits_to_f32(beta[tid]);
+    }
+    const long long nsteps = (M + kLinRows - 1) / kLinRows;
+    long long step = (long long)blockIdx.x * kLnlWaves + wave;
+    const long long stride = (long long)gridDim.x * kLnlWaves;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; step < nsteps; step += stride) {
+        const long long row_a = step * kLinRows + col, row_b = row_a + 16;
+        u32x4 xc[2][8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            xc[0][s] = row_a < M ? *reinterpret_cast<const u32x4 *>(x + row_a * ldx + 32 * s + 8 * g) : u32x4{0u, 0u, 0u, 0u};
+            xc[1][s] = row_b < M ? *reinterpret_cast<const u32x4 *>(x + row_b * ldx + 32 * s + 8 * g) : u32x4{0u, 0u, 0u, 0u};
+        }
+        f32x4 acc[16][2];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 32 * (t >> 1) + 8 * g + 4 * (t & 1));
+            acc[t][0] = b4;
+            acc[t][1] = b4;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const ln_bf16x8 a = __builtin_bit_cast(ln_bf16x8, wl[(t * 8 + s) * 64 + lane]);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[0][s]), acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[1][s]), acc[t][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                                // one k-step's 16 fragments in flight at a time
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const long long row = cb ? row_b : row_a;
+            const bool ok = row < M;
+            // v = round_bf16(projection) + residual (the unfused path stores the projection in bf16 first); fp32 two-pass statistics
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const u32x4 r = ok ? *reinterpret_cast<const u32x4 *>(res + row * ldr + 32 * u + 8 * g) : u32x4{0u, 0u, 0u, 0u};
+                f32x4 &lo = acc[2 * u][cb], &hi = acc[2 * u + 1][cb];
+                const unsigned p0 = pack_bf16x2(lo.x, lo.y), p1 = pack_bf16x2(lo.z, lo.w), p2 = pack_bf16x2(hi.x, hi.y), p3 = pack_bf16x2(hi.z, hi.w);
+                lo.x = __builtin_bit_cast(float, p0 << 16) + __builtin_bit_cast(float, r.x << 16);
+                lo.y = __builtin_bit_cast(float, p0 & 0xffff0000u) + __builtin_bit_cast(float, r.x & 0xffff0000u);
+                lo.z = __builtin_bit_cast(float, p1 << 16) + __builtin_bit_cast(float, r.y << 16);
+                lo.w = __builtin_bit_cast(float, p1 & 0xffff0000u) + __builtin_bit_cast(float, r.y & 0xffff0000u);
+                hi.x = __builtin_bit_cast(float, p2 << 16) + __builtin_bit_cast(float, r.z << 16);
+                hi.y = __builtin_bit_cast(float, p2 & 0xffff0000u) + __builtin_bit_cast(float, r.z & 0xffff0000u);
+                hi.z = __builtin_bit_cast(float, p3 << 16) + __builtin_bit_cast(float, r.w << 16);
+                hi.w = __builtin_bit_cast(float, p3 & 0xffff0000u) + __builtin_bit_cast(float, r.w & 0xffff0000u);
+                sum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / 256.0f);
+            float sq = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                f32x4 &lo = acc[2 * u][cb], &hi = acc[2 * u + 1][cb];
+                lo.x -= mean; lo.y -= mean; lo.z -= mean; lo.w -= mean;
+                hi.x -= mean; hi.y -= mean; hi.z -= mean; hi.w -= mean;
+                sq += ((lo.x * lo.x + lo.y * lo.y) + (lo.z * lo.z + lo.w * lo.w)) + ((hi.x * hi.x + hi.y * hi.y) + (hi.z * hi.z + hi.w * hi.w));
+            }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / 256.0f) + eps);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 lo = acc[2 * u][cb], hi = acc[2 * u + 1][cb];
+                const float *gp = bl + 256 + 32 * u + 8 * g, *bp = bl + 512 + 32 * u + 8 * g;
+                const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gp), g1 = *reinterpret_cast<const f32x4 *>(gp + 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(bp), c1 = *reinterpret_cast<const f32x4 *>(bp + 4);
+                u32x4 pk;
+                pk.x = pack_bf16x2(lo.x * rstd * g0.x + c0.x, lo.y * rstd * g0.y + c0.y);
+                pk.y = pack_bf16x2(lo.z * rstd * g0.z + c0.z, lo.w * rstd * g0.w + c0.w);
+                pk.z = pack_bf16x2(hi.x * rstd * g1.x + c1.x, hi.y * rstd * g1.y + c1.y);
+                pk.w = pack_bf16x2(hi.z * rstd * g1.z + c1.z, hi.w * rstd * g1.w + c1.w);
+                if (ok) *reinterpret_cast<u32x4 *>(out + row * ldo + 32 * u + 8 * g) = pk;
+            }
+        }
+    }
+}
+
 }  // namespace rdetr
 
 using namespace rdetr;
@@ -170,4 +298,38 @@ extern "C" int rdetr_linear_k256_bf16(const uint16_t *x, long long ldx, const ui
     const int chunks = N / 192;
     return relu ? linear_launch<12, true>(x, ldx, w, bias, M, N, out, ldo, chunks, st)
                 : linear_launch<12, false>(x, ldx, w, bias, M, N, out, ldo, chunks, st);
+}
+
+// packed <- w [256, 256] in the fragment order rdetr_linear_ln_k256_bf16 reads (65,536 bf16 elements, 16-byte aligned)
+extern "C" int rdetr_linear_pack_k256_bf16(const uint16_t *w, uint16_t *packed, void *stream)
+{
+    if (!w || !packed) return RDETR_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(packed)) & 15) return RDETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(linear_pack_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream), w, reinterpret_cast<u32x4 *>(packed));
+    return launch_status();
+}
+
+// out[M, 256] = LayerNorm(residual + (x[M, 256] w^T + bias)) with w packed by rdetr_linear_pack_k256_bf16; gamma / beta [256];
+// the projection is rounded to bf16 before the residual is added (as the unfused path stores it); fp32 statistics.
+extern "C" int rdetr_linear_ln_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *bias,
+                                         const uint16_t *residual, long long ldr, const uint16_t *gamma, const uint16_t *beta,
+                                         float eps, long long M, uint16_t *out, long long ldo, void *stream)
+{
+    if (M < 0 || ldx < kLinK || ldr < kLinK || ldo < kLinK) return RDETR_ERR_INVALID_ARG;
+    if ((ldx & 7) || (ldr & 7) || (ldo & 7)) return RDETR_ERR_UNSUPPORTED;
+    if (M == 0) return RDETR_OK;
+    if (!x || !packed || !residual || !gamma || !beta || !out) return RDETR_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(residual) |
+         reinterpret_cast<uintptr_t>(out)) & 15)
+        return RDETR_ERR_UNSUPPORTED;
+    constexpr int lds = 16 * 8 * 64 * 16 + 3 * 256 * 4;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_ln_k256_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return RDETR_ERR_LAUNCH;
+    const long long steps = (M + kLinRows - 1) / kLinRows;
+    long long gx = (steps + kLnlWaves - 1) / kLnlWaves;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(linear_ln_k256_kernel, dim3((unsigned)gx), dim3(kLnlThreads), (size_t)lds, static_cast<hipStream_t>(stream), x,
+                       ldx, packed, bias, residual, ldr, gamma, beta, eps, M, out, ldo);
+    return launch_status();
 }

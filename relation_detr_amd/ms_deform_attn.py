@@ -132,9 +132,12 @@ class MultiScaleDeformableAttention(nn.Module):
         return v, sampling_locations(reference_points, offsets, spatial_shapes, self.num_points), weights
 
     def forward(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
-                level_start_index: Tensor, key_padding_mask: Tensor) -> Tensor:
+                level_start_index: Tensor, key_padding_mask: Tensor, post_norm=None) -> Tensor:
         """query [B,Nq,C]; reference_points [B,Nq,L,2] or [B,Nq,L,4]; value [B,S,C]; spatial_shapes
-        [L,2] (h,w); level_start_index [L]; key_padding_mask [B,S] bool or None -> [B,Nq,C]."""
+        [L,2] (h,w); level_start_index [L]; key_padding_mask [B,S] bool or None -> [B,Nq,C].
+        ``post_norm = (residual, layer_norm)`` (not in the reference's signature, optional): return
+        ``layer_norm(residual + output)`` -- the caller's next two steps (relation_transformer.py:270-271) -- which tall bf16
+        inference inputs get from the output projection's own epilogue (csrc/linear.hip)."""
         if value.is_cuda:      # same consistency check as the reference (:313), from a cached host copy
             shapes, _ = ops.host_levels(spatial_shapes, level_start_index)
             assert sum(h * w for h, w in shapes) == value.shape[1]
@@ -174,4 +177,14 @@ class MultiScaleDeformableAttention(nn.Module):
                 weights.float().contiguous(), self.im2col_step)
         if core.dtype != v.dtype:
             core = core.to(v.dtype)
-        return self.output_proj(core)
+        if post_norm is None:
+            return self.output_proj(core)
+        residual, norm = post_norm
+        if (core.is_cuda and not torch.is_grad_enabled() and core.numel() // core.shape[-1] >= 16384
+                and os.environ.get("RDETR_PROJ_LN", "1") != "0" and norm.weight is not None and norm.bias is not None
+                and ops.linear_ln_k256_supported(core, self.output_proj.weight, residual)):
+            return ops.linear_ln_k256(core, self.output_proj.weight, self.output_proj.bias, residual, norm.weight, norm.bias, norm.eps)
+        out = self.output_proj(core)
+        if out.is_cuda and not torch.is_grad_enabled() and out.dtype in (torch.float32, torch.bfloat16):
+            return ops.add_layer_norm(out, residual, norm.weight, norm.bias, norm.eps)
+        return norm(residual + out)

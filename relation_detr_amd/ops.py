@@ -695,3 +695,55 @@ def ffn_ln_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.T
                                             None if out2 is None else out2.data_ptr(), 256, _stream_ptr(x))
     _lib.check(st, "rdetr_ffn_ln_k256_bf16")
     return out if pos is None else (out, out2)
+
+
+_LINEAR_PACKED = {}     # weight ptr -> (version, packed)
+
+
+def linear_ln_k256_supported(x: torch.Tensor, weight: torch.Tensor, residual: torch.Tensor) -> bool:
+    if not (linear_k256_supported(x, weight) and tuple(weight.shape) == (256, 256) and residual.dtype == torch.bfloat16
+            and residual.is_cuda and tuple(residual.shape) == tuple(x.shape)):
+        return False
+    try:
+        _, _, ldr = _rows_view(residual, "linear_ln_k256")
+    except _lib.RdetrError:
+        return False
+    return ldr % 8 == 0 and residual.data_ptr() % 16 == 0
+
+
+def linear_ln_k256(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], residual: torch.Tensor,
+                   gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``LayerNorm(residual + F.linear(x, weight, bias))`` for bf16 [..., 256] tensors and a [256, 256] weight in one kernel
+    (MSDA's output_proj + the layer's norm1, ms_deform_attn.py:372-376 / relation_transformer.py:262-271).  Inference only."""
+    _require_device(x, weight, bias, residual, gamma, beta, out)
+    if not linear_ln_k256_supported(x, weight, residual):
+        raise _lib.RdetrError("linear_ln_k256: needs bf16 [..., 256] inputs with evenly strided 16-byte aligned rows and a [256, 256] weight")
+    for t in (bias, gamma, beta):
+        if t is not None and (t.dtype != torch.bfloat16 or t.numel() != 256):
+            raise _lib.RdetrError("linear_ln_k256: bias / gamma / beta must be bf16 [256]")
+    rows, _, ldx = _rows_view(x, "linear_ln_k256")
+    _, _, ldr = _rows_view(residual, "linear_ln_k256")
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != tuple(x.shape) or out.dtype != x.dtype:
+        raise _lib.RdetrError("linear_ln_k256: out must have x's shape and dtype")
+    orows, _, ldo = _rows_view(out, "linear_ln_k256")
+    if orows != rows or ldo % 8 or out.data_ptr() % 16:
+        raise _lib.RdetrError("linear_ln_k256: out rows must be 16-byte aligned")
+    lib = _lib.load()
+    key, ver = (weight.data_ptr(), weight.device), weight._version
+    hit = _LINEAR_PACKED.get(key)
+    if hit is None or hit[0] != ver:
+        packed = torch.empty(256 * 256, dtype=torch.bfloat16, device=weight.device)
+        _lib.check(lib.rdetr_linear_pack_k256_bf16(weight.data_ptr(), packed.data_ptr(), _stream_ptr(weight)), "rdetr_linear_pack_k256_bf16")
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(weight.device).synchronize()
+        if len(_LINEAR_PACKED) > 64:
+            _LINEAR_PACKED.clear()
+        hit = (ver, packed)
+        _LINEAR_PACKED[key] = hit
+    st = lib.rdetr_linear_ln_k256_bf16(x.data_ptr(), ldx, hit[1].data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
+                                       residual.data_ptr(), ldr, gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(),
+                                       float(eps), rows, out.data_ptr(), ldo, _stream_ptr(x))
+    _lib.check(st, "rdetr_linear_ln_k256_bf16")
+    return out

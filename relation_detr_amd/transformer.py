@@ -143,10 +143,15 @@ class RelationTransformerEncoderLayer(nn.Module):
         (the next layer's `query_plus_pos`), produced by the final add+LayerNorm pass -> (output, output + next_pos)."""
         if query_plus_pos is None:
             query_plus_pos = query if query_pos is None else query + query_pos
-        attn = self.self_attn(query=query_plus_pos, reference_points=reference_points,
-                              value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                              key_padding_mask=key_padding_mask)
-        query = add_norm(self.norm1, query, attn)
+        if type(self.self_attn).forward is MultiScaleDeformableAttention.forward:       # not a subclass with its own forward
+            query = self.self_attn(query=query_plus_pos, reference_points=reference_points, value=query,
+                                   spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                   key_padding_mask=key_padding_mask, post_norm=(query, self.norm1))     # norm1(query + attn)
+        else:
+            attn = self.self_attn(query=query_plus_pos, reference_points=reference_points,
+                                  value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                  key_padding_mask=key_padding_mask)
+            query = add_norm(self.norm1, query, attn)
         if _fused_ffn_applies(self.linear1, self.linear2, query) and os.environ.get("RDETR_FFN_LN", "0") == "1":
             # opt-in: feed-forward block, residual, LayerNorm (and the next layer's query + pos) in ONE kernel (csrc/ffn.hip).
             # Correct (tests/test_gpu_glue.py) but 1 % slower than fused FFN + the add+LayerNorm kernel: the epilogue's

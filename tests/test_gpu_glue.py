@@ -416,3 +416,24 @@ def test_ffn_ln_k256_is_ffn_then_add_layer_norm():
         wide = torch.zeros(*shape[:2], 3 * 256, device=DEV, dtype=torch.bfloat16)
         o, o2 = ops.ffn_ln_k256(x, w1, b1, w2, b2, gamma, beta, 1e-5, out=wide[..., 256:512], pos=pos)
         assert torch.equal(o, got) and torch.equal(o2, got + pos) and not wide[..., :256].any() and not wide[..., 512:].any()
+
+
+def test_linear_ln_k256_is_linear_then_add_layer_norm():
+    """output_proj + residual + LayerNorm in one kernel against F.linear (fp32 product, rounded to bf16) + ops.add_layer_norm."""
+    from relation_detr_amd import ops
+    torch.manual_seed(9)
+    w = (torch.randn(256, 256, device=DEV) * 0.06).bfloat16()
+    b = torch.randn(256, device=DEV).bfloat16()
+    gamma, beta = torch.randn(256, device=DEV).bfloat16(), torch.randn(256, device=DEV).bfloat16()
+    for shape in ((2, 22323, 256), (1, 37, 256), (3, 1, 256)):
+        x = torch.randn(*shape, device=DEV).bfloat16()
+        res = torch.randn(*shape, device=DEV).bfloat16()
+        proj = (x.float() @ w.float().t() + b.float()).bfloat16()
+        want = ops.add_layer_norm(res, proj, gamma, beta, 1e-5)
+        got = ops.linear_ln_k256(x, w, b, res, gamma, beta, 1e-5)
+        err = (got.float() - want.float()).abs()
+        assert float(err.max()) <= 2 ** -5 and float(err.mean()) <= 2e-4           # flipped bf16 roundings of the projection
+        wide = torch.zeros(*shape[:2], 3 * 256, device=DEV, dtype=torch.bfloat16)
+        buf = torch.randn(*shape[:2], 2 * 256, device=DEV).bfloat16()
+        o = ops.linear_ln_k256(x, w, b, buf[..., 256:], gamma, beta, 1e-5, out=wide[..., :256])
+        assert torch.equal(o, ops.linear_ln_k256(x, w, b, buf[..., 256:].contiguous(), gamma, beta, 1e-5)) and not wide[..., 256:].any()

@@ -11,6 +11,8 @@ tail -1 gpurun_out/final/bench_default_bf16.json.log | cut -c1-260
 python3 bench.py --dtype fp32 --no-cpu-baseline > gpurun_out/final/bench_fp32.json.log 2>/dev/null
 tail -1 gpurun_out/final/bench_fp32.json.log | cut -c1-260
 RDETR_BENCH_STREAMS=1 python3 bench.py --no-cpu-baseline > gpurun_out/final/bench_bf16_one_stream.json.log 2>/dev/null
+RDETR_BENCH_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final/bench_bf16_one_rank_rccl.json.log 2>/dev/null
+tail -1 gpurun_out/final/bench_bf16_one_rank_rccl.json.log | cut -c1-200
 tail -1 gpurun_out/final/bench_bf16_one_stream.json.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export RDETR_BENCH_TUNABLEOP=0 RDETR_BENCH_STREAMS=1 RDETR_BENCH_ALT300=0

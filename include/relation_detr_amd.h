@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RDETR_ABI_VERSION 1
+#define RDETR_ABI_VERSION 2
 
 typedef enum rdetr_status {
     RDETR_OK = 0,
@@ -82,22 +82,10 @@ int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_t *spatial_
                                   const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B, int S,
                                   int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
 
-/* Fused-producer form with `key_padding_mask` (u8 [B, S], non-zero = padded position, may be NULL) applied inside the
+/* General fused-producer form.  `key_padding_mask` (u8 [B, S], non-zero = padded position, may be NULL) is applied inside the
  * gather: a padded pixel's row counts as zero, which is what zero-filling the projected value does
- * (models/bricks/ms_deform_attn.py:316-319) -- without a pass over the [B, S, H*D] tensor.  Fast-path shapes only. */
-int rdetr_msda_forward_fused_masked_f32(const float *value, const int64_t *spatial_shapes,
-                                        const int64_t *level_start_index, const float *sampling_offsets,
-                                        const float *attn_logits, const float *reference_points, int ref_dim,
-                                        const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
-                                        float *out, void *stream);
-int rdetr_msda_forward_fused_masked_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                         const int64_t *level_start_index, const uint16_t *sampling_offsets,
-                                         const uint16_t *attn_logits, const float *reference_points, int ref_dim,
-                                         const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
-                                         uint16_t *out, void *stream);
-
-/* General fused-producer form: as rdetr_msda_forward_fused_masked_* plus ROW STRIDES (in elements; 0 = contiguous) of the
- * two projection outputs, so that sampling_offsets and attention_weights can be the column slices [0, 2*H*L*P) and
+ * (models/bricks/ms_deform_attn.py:316-319) -- without a pass over the [B, S, H*D] tensor.  ROW STRIDES (in elements;
+ * 0 = contiguous) of the two projection outputs, so that sampling_offsets and attention_weights can be the column slices [0, 2*H*L*P) and
  * [2*H*L*P, 3*H*L*P) of ONE [rows, 3*H*L*P] GEMM output (one projection GEMM instead of two).  ld_offsets must be even
  * (offsets are read as (x, y) pairs). */
 int rdetr_msda_forward_fused_ex_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
@@ -110,58 +98,42 @@ int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spati
                                      const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
                                      uint16_t *out, void *stream);
 
-/* "Planned" forms of the four entry points above (H = 8, D = 32, P = 4 implied; L <= 8): identical
- * arithmetic and results, plus `host_spatial_shapes`, a HOST copy of the [L,2] (h,w) table, so that the launch can
- * be planned around the pyramid geometry (levels packed contiguously, level_start = running sum).  The reference
- * operator reads the table on the device only (ms_deform_im2col_cuda.cuh:263-267); callers that already hold it on
- * the host (relation_detr_amd/ops.py caches one copy per pyramid) should prefer these.
- * Strategy, environment RDETR_MSDA_ALGO (read once; DESIGN.md section 4.2 has the measurements):
- *   "qrun" (default)  the direct query-run kernel of rdetr_msda_forward_* -- the fastest of the four in round 1;
- *   "hybrid"          csrc/msda_hybrid.hip when L == 4 and Nq >= 1024: the planes of the coarsest levels are kept
- *                     in LDS and gathered from there, the fine levels by range-checked global loads;
- *   "tile2d", "sweep" strategies for Nq == S (queries = the pyramid's pixels): 2-D patch per workgroup / LDS band
- *                     kernel (csrc/msda_sweep.hip).
- * The alternatives are experimental: parity-tested, not faster. */
-int rdetr_msda_forward_planned_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
-                                   const int64_t *host_spatial_shapes, const float *sampling_loc,
-                                   const float *attn_weight, int B, int S, int L, int Nq, float *out, void *stream);
-int rdetr_msda_forward_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                    const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                    const float *sampling_loc, const float *attn_weight, int B, int S, int L, int Nq,
-                                    uint16_t *out, void *stream);
-int rdetr_msda_forward_fused_planned_f32(const float *value, const int64_t *spatial_shapes,
-                                         const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                         const float *sampling_offsets, const float *attn_logits,
-                                         const float *reference_points, int ref_dim, int B, int S, int L, int Nq,
-                                         float *out, void *stream);
-int rdetr_msda_forward_fused_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                          const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                          const uint16_t *sampling_offsets, const uint16_t *attn_logits,
-                                          const float *reference_points, int ref_dim, int B, int S, int L, int Nq,
-                                          uint16_t *out, void *stream);
+/* bf16 operator (both producer forms) with the VALUE LAYOUT and the KERNEL CHOICE as explicit arguments -- the library
+ * reads no environment variable and keeps no state.
+ *   value_layout  RDETR_VALUE_BSHD  value [B, S, H, D]: the reference operator's layout (ms_deform_attn_cuda.cu:12-19);
+ *                 RDETR_VALUE_BHSD  value [B, H, S, D]: head-major -- one (image, head) plane is contiguous, so the window
+ *                                   kernel fills its LDS windows at the contiguous-row rate.  Written by
+ *                                   rdetr_value_to_head_major_bf16 (below); fast-path shapes only.
+ *   algo          RDETR_MSDA_AUTO    the window kernel where it applies, else the direct kernel (what the plain entry
+ *                                    points do);
+ *                 RDETR_MSDA_DIRECT  csrc/msda_fwd.hip -- the query-run kernel (range-checked global gathers), any Nq, L <= 8;
+ *                 RDETR_MSDA_WINDOW  csrc/msda_win.hip -- LDS-window MFMA kernel for the ENCODER shape: queries are the
+ *                                    pyramid's own pixels in level_start order (Nq == S), L == 4, S >= 4096, no padding
+ *                                    mask.  Per 16 x 12 query tile and level a 32-pixel-wide window of the value plane is
+ *                                    copied L2 -> LDS by range-checked LDS-DMA (pixels outside the level arrive as zeros) and
+ *                                    gathered from there on the matrix cores; samples outside their window are fetched from
+ *                                    global memory, so results never depend on the windows.  RDETR_ERR_UNSUPPORTED for any
+ *                                    other shape.
+ * Results of the two kernels agree to the rounding of the bf16 output (different summation order). */
+#define RDETR_VALUE_BSHD 0
+#define RDETR_VALUE_BHSD 1
+#define RDETR_MSDA_AUTO 0
+#define RDETR_MSDA_DIRECT 1
+#define RDETR_MSDA_WINDOW 2
+int rdetr_msda_forward_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
+                                const int64_t *level_start_index, const float *sampling_loc, const float *attn_weight, int B,
+                                int S, int H, int D, int L, int Nq, int P, int algo, uint16_t *out, void *stream);
+int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
+                                      const int64_t *level_start_index, const uint16_t *sampling_offsets, int ld_offsets,
+                                      const uint16_t *attn_logits, int ld_logits, const float *reference_points, int ref_dim,
+                                      const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
+                                      int algo, uint16_t *out, void *stream);
 
-/* Explicit-strategy forms of the bf16 operator (H = 8, D = 32, P = 4 implied), for A/B measurement and tests; the
- * plain entry points above choose between the two themselves (RDETR_MSDA_ALGO=q forces "direct"):
- *   *_tiled_*   csrc/msda_tile.hip -- LDS-tiled kernel for the ENCODER shape: queries are the pyramid's own pixels in
- *               level_start order (Nq == S), L == 4, S >= 4096.  Per 16x16 query tile and level, the window of the
- *               value plane the tile samples (bounding box of its actual sample corners, clipped to the LDS buffer)
- *               is copied L2 -> LDS by LDS-DMA and gathered from there; samples outside the window are fetched from
- *               global memory, so results never depend on the window.  RDETR_ERR_UNSUPPORTED for any other shape.
- *   *_direct_*  csrc/msda_fwd.hip -- the query-run kernel (range-checked global gathers), any Nq, L <= 8. */
-int rdetr_msda_forward_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
-                                  const float *sampling_loc, const float *attn_weight, int B, int S, int L, int Nq,
-                                  uint16_t *out, void *stream);
-int rdetr_msda_forward_fused_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                        const int64_t *level_start_index, const uint16_t *sampling_offsets,
-                                        const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B,
-                                        int S, int L, int Nq, uint16_t *out, void *stream);
-int rdetr_msda_forward_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
-                                   const float *sampling_loc, const float *attn_weight, int B, int S, int L, int Nq,
-                                   uint16_t *out, void *stream);
-int rdetr_msda_forward_fused_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                         const int64_t *level_start_index, const uint16_t *sampling_offsets,
-                                         const uint16_t *attn_logits, const float *reference_points, int ref_dim, int B,
-                                         int S, int L, int Nq, uint16_t *out, void *stream);
+/* Projected value [B, S, H*D] bf16 (rows `ld` elements apart, ld % 8 == 0: the rows may be a column slice of a wider
+ * buffer) -> head-major [B, H, S, D], with the rows of padded positions (`key_padding_mask` u8 [B, S], may be NULL)
+ * written as zeros -- the zero-fill of models/bricks/ms_deform_attn.py:316-319 folded into the re-layout.  H = 8, D = 32. */
+int rdetr_value_to_head_major_bf16(const uint16_t *src, long long ld, const uint8_t *key_padding_mask, int B, int S, int H,
+                                   int D, uint16_t *dst, void *stream);
 
 /* 1 if (H, D, L, P) is served by the query-run kernel, 0 if by the generic kernel. */
 int rdetr_msda_fast_path(int H, int D, int L, int P);

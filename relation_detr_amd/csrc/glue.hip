@@ -151,7 +151,8 @@ extern "C" int rdetr_box_refine_f32(const void *delta, int delta_is_bf16, const 
 extern "C" int rdetr_sine_pos_embed(const float *pos, long long rows, int n, int F, float temperature, float scale, void *out,
                                     int out_is_bf16, void *stream)
 {
-    if (rows < 0 || n <= 0 || F <= 0) return RDETR_ERR_INVALID_ARG;
+    // n >= 2: the first two coordinates are exchanged (exchange_xy=True); the reference's index_select fails for n == 1 too
+    if (rows < 0 || n < 2 || F <= 0) return RDETR_ERR_INVALID_ARG;
     if ((F & 1) || F > 128) return RDETR_ERR_UNSUPPORTED;
     if (rows == 0) return RDETR_OK;
     if (!pos || !out) return RDETR_ERR_INVALID_ARG;

@@ -119,8 +119,8 @@ template <typename T, int LT, bool FUSED>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
-    int L_rt, int Nq, int tiles_per_image, int nblk, int tile2d, T *__restrict__ out,
-    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b)
+    int L_rt, int Nq, int tiles_per_image, int nblk, T *__restrict__ out,
+    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
@@ -151,28 +151,17 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int qs = lane / kSub, sub = lane % kSub;
-    int q = (tile * kWavesPerBlock + wave) * kSlots + qs;
-    bool qok = q < Nq;
-    if (tile2d) {
-        // encoder order (queries = pyramid pixels): the block covers a kSlots-wide x 4-row patch of ONE level, one
-        // row per wave, so the rows y0+1 of wave r are the rows y0 of wave r+1: vertical re-use inside the CU's L1
-        int r = tile, lq = 0, ntx = 1;
-        for (int l = 0; l < L; ++l) {
-            ntx = (lvl.w[l] + kSlots - 1) / kSlots;
-            const int nt = ntx * ((lvl.h[l] + kWavesPerBlock - 1) / kWavesPerBlock);
-            lq = l;
-            if (r < nt) break;
-            r -= nt;
-        }
-        const int ty = r / ntx, tx = r - ty * ntx;
-        const int x = tx * kSlots + qs, y = ty * kWavesPerBlock + wave;
-        qok = x < lvl.w[lq] && y < lvl.h[lq];
-        q = qok ? lvl.start[lq] + y * lvl.w[lq] + x : 0;
-    }
+    const int q = (tile * kWavesPerBlock + wave) * kSlots + qs;
+    const bool qok = q < Nq;
 
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T *>(value) + (size_t)b * S * (kHeads * kHeadDim) + m * kHeadDim, 0,
-        (unsigned)S * IO::kPixelBytes - (unsigned)m * IO::kHeadBytes, 0x00020000);
+    // value [B,S,H,D] (the reference operator's layout: a pixel's heads side by side) or, head_major, [B,H,S,D]: either way
+    // the (image, head) plane sits behind one wave-uniform buffer descriptor and a pixel step is `pixb` bytes
+    const unsigned pixb = head_major ? IO::kHeadBytes : IO::kPixelBytes;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        head_major ? __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value) + ((size_t)b * kHeads + m) * (size_t)S * kHeadDim, 0,
+                                                       (unsigned)S * IO::kHeadBytes, 0x00020000)
+                   : __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value) + (size_t)b * S * (kHeads * kHeadDim) + m * kHeadDim, 0,
+                                                       (unsigned)S * IO::kPixelBytes - (unsigned)m * IO::kHeadBytes, 0x00020000);
     const unsigned lane_off = (unsigned)sub * 16u;
 
     u32x4 *soff = stage_off[wave];
@@ -245,13 +234,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
             const bool okx0 = inside && x0 >= 0, okx1 = inside && x0 + 1 <= w - 1;
             const bool oky0 = y0 >= 0, oky1 = y0 + 1 <= h - 1;
-            const unsigned base = (unsigned)(lvl.start[l] + y0 * w + x0) * IO::kPixelBytes;
-            const unsigned rowb = (unsigned)w * IO::kPixelBytes;
+            const unsigned base = (unsigned)(lvl.start[l] + y0 * w + x0) * pixb;
+            const unsigned rowb = (unsigned)w * pixb;
             u32x4 o;
             o.x = (okx0 && oky0) ? base : kInvalidOffset;
-            o.y = (okx1 && oky0) ? base + IO::kPixelBytes : kInvalidOffset;
+            o.y = (okx1 && oky0) ? base + pixb : kInvalidOffset;
             o.z = (okx0 && oky1) ? base + rowb : kInvalidOffset;
-            o.w = (okx1 && oky1) ? base + rowb + IO::kPixelBytes : kInvalidOffset;
+            o.w = (okx1 && oky1) ? base + rowb + pixb : kInvalidOffset;
             if (pad_mask) {                  // key_padding_mask: a padded pixel's projected value row counts as zero
                 const unsigned char *mp = pad_mask + (size_t)b * S + (lvl.start[l] + y0 * w + x0);     // (ms_deform_attn.py:316-319)
                 if (okx0 && oky0 && mp[0]) o.x = kInvalidOffset;
@@ -355,94 +344,111 @@ static bool fast_path(int H, int D, int L, int P)
     return H == kHeads && D == kHeadDim && P == kPoints && L >= 1 && L <= kMaxLevels;
 }
 
-// csrc/msda_tile.hip: LDS-tiled kernel for the encoder shape (bf16, L == 4, Nq == S).
-template <bool FUSED>
-int msda_tile_forward(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
-                      const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, uint16_t *out,
-                      hipStream_t stream);
-
-// RDETR_MSDA_ALGO (read once): q(run, default) = the direct query-run kernel;  l(ds) = the LDS-tiled kernel
-// (csrc/msda_tile.hip) where it applies (bf16, L == 4, Nq == S);  h / t / s = the experimental strategies behind the
-// planned entry points.
-static char msda_algo()
-{
-    static const char algo = []() {
-        const char *e = getenv("RDETR_MSDA_ALGO");
-        return e ? e[0] : 'q';
-    }();
-    return algo;
-}
+// csrc/msda_win.hip: LDS-window MFMA kernel for the encoder shape (bf16, L == 4, Nq == S).
+template <bool FUSED, bool HM>
+int msda_win_forward(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
+                     const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, int ld_a, int ld_b,
+                     uint16_t *out, hipStream_t stream);
 
 template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
-                        int S, int L, int Nq, int tiles, int nblk, int tile2d, T *out, const unsigned char *pad_mask, int ld_a,
-                        int ld_b)
+                        int S, int L, int Nq, int tiles, int nblk, T *out, const unsigned char *pad_mask, int ld_a, int ld_b,
+                        int head_major)
 {
     if (L == 4)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask, ld_a, ld_b);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
     else if (L == 5)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask, ld_a, ld_b);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
     else
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, tile2d, out, pad_mask, ld_a, ld_b);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
 // FUSED = true : src_a / src_b = raw offsets / logits in T, ref = reference points; fast-path shapes only.
+// layout: RDETR_VALUE_BSHD | RDETR_VALUE_BHSD.  algo: RDETR_MSDA_AUTO | _DIRECT | _WINDOW (explicit arguments -- the library
+// reads no environment and keeps no state).
 template <typename T, bool FUSED>
-static int msda_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
+static int msda_forward(const T *value, int layout, const int64_t *shapes, const int64_t *level_start, const void *src_a,
                         const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
-                        int P, T *out, hipStream_t stream, const int64_t *host_shapes = nullptr, bool force_direct = false,
-                        const unsigned char *pad_mask = nullptr, int ld_a = 0, int ld_b = 0)
+                        int P, T *out, hipStream_t stream, int algo = RDETR_MSDA_AUTO, const unsigned char *pad_mask = nullptr,
+                        int ld_a = 0, int ld_b = 0)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
+    if (layout != RDETR_VALUE_BSHD && layout != RDETR_VALUE_BHSD) return RDETR_ERR_INVALID_ARG;
+    if (algo != RDETR_MSDA_AUTO && algo != RDETR_MSDA_DIRECT && algo != RDETR_MSDA_WINDOW) return RDETR_ERR_INVALID_ARG;
     if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
     if (B == 0 || Nq == 0) return RDETR_OK;
     if (!value || !shapes || !level_start || !src_a || !src_b || !out || (FUSED && !ref)) return RDETR_ERR_INVALID_ARG;
     if (S == 0) return RDETR_ERR_INVALID_ARG;
+    const bool hm = layout == RDETR_VALUE_BHSD;
 
     const long long pixel_bytes = (long long)H * D * (long long)sizeof(T);
     const bool aligned = (reinterpret_cast<uintptr_t>(value) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
         if constexpr (sizeof(T) == 2) {
-            if (msda_algo() == 'l' && !host_shapes && !force_direct && !pad_mask && !ld_a && !ld_b) {
-                const int st = msda_tile_forward<FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, L, Nq,
-                                                        out, stream);
+            // encoder shape (queries = the pyramid's own pixels): the LDS-window MFMA kernel
+            if (algo != RDETR_MSDA_DIRECT && !pad_mask) {
+                const int st = hm ? msda_win_forward<FUSED, true>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S,
+                                                                  L, Nq, ld_a, ld_b, out, stream)
+                                  : msda_win_forward<FUSED, false>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B,
+                                                                   S, L, Nq, ld_a, ld_b, out, stream);
                 if (st != RDETR_ERR_UNSUPPORTED) return st;
             }
         }
+        if (algo == RDETR_MSDA_WINDOW) return RDETR_ERR_UNSUPPORTED;
         const int slots = kWave / ValueIO<T>::kRunSub;                       // queries per wave (8 fp32 / 16 bf16)
         const int qpb = kWavesPerBlock * slots;
-        long long tiles = (Nq + qpb - 1) / qpb;
-        int tile2d = 0;
-        if (host_shapes) {        // encoder order: 2-D patches (slots wide x 4 rows) per level instead of 1-D runs
-            long long t2 = 0, tot = 0;
-            for (int l = 0; l < L; ++l) {
-                const long long h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
-                t2 += ((w + slots - 1) / slots) * ((h + kWavesPerBlock - 1) / kWavesPerBlock);
-                tot += h * w;
-            }
-            if (tot != S || Nq != S) return RDETR_ERR_INVALID_ARG;
-            tiles = t2;
-            tile2d = 1;
-        }
+        const long long tiles = (Nq + qpb - 1) / qpb;
         const long long nblk = (long long)B * H * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
         launch_qrun<T, FUSED>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
-                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, tile2d, out, pad_mask, ld_a, ld_b);
+                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, out, pad_mask, ld_a, ld_b, hm ? 1 : 0);
         return launch_status();
     }
-    if (FUSED || pad_mask || ld_a || ld_b) return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
+    if (FUSED || pad_mask || ld_a || ld_b || hm || algo == RDETR_MSDA_WINDOW)
+        return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
     const long long total = (long long)B * Nq * H * D;
     const long long want = (total + 255) / 256;
     dim3 grid((unsigned)(want < 16384 ? want : 16384)), block(256);
     hipLaunchKernelGGL((msda_fwd_generic_kernel<T>), grid, block, 0, stream, value, shapes, level_start,
                        static_cast<const float *>(src_a), static_cast<const float *>(src_b), S, H, D, L, Nq, P, total, out);
     return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// [B,S,H*D] rows (row stride `ld` elements) -> head-major [B,H,S,D], rows of padded positions zeroed on the way
+// (ms_deform_attn.py:316-319): the layout the window kernel fills its LDS windows from at the contiguous-row rate.
+// One workgroup = 64 positions: coalesced 512-byte row reads, LDS transpose, coalesced 4-KiB head runs out.
+__global__ __launch_bounds__(256) void value_to_head_major_kernel(const uint16_t *__restrict__ src, long long ld,
+                                                                  const unsigned char *__restrict__ mask, int S,
+                                                                  uint16_t *__restrict__ dst)
+{
+    __shared__ u32x4 tile[64 * 32 + 64];                                   // 64 positions x 32 chunks of 16 B (+ skew)
+    const int b = blockIdx.y, s0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int n = S - s0 < 64 ? S - s0 : 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + i * 256, r = e >> 5, c = e & 31;               // position r, 16-byte chunk c (head c >> 2)
+        if (r < n) {
+            u32x4 v = *reinterpret_cast<const u32x4 *>(src + ((size_t)b * S + s0 + r) * (size_t)ld + c * 8);
+            if (mask && mask[(size_t)b * S + s0 + r]) v = u32x4{0u, 0u, 0u, 0u};
+            tile[r * 32 + (c ^ (r & 31))] = v;                             // skew: the transposed read below is conflict-free
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + i * 256, h = e >> 8, r = (e >> 2) & 63, k = e & 3;      // head h: 64 positions x 4 chunks, contiguous
+        if (r < n) {
+            const int c = h * 4 + k;
+            *reinterpret_cast<u32x4 *>(dst + (((size_t)b * kHeads + h) * (size_t)S + s0 + r) * kHeadDim + k * 8) = tile[r * 32 + (c ^ (r & 31))];
+        }
+    }
 }
 
 }  // namespace rdetr
@@ -454,8 +460,8 @@ extern "C" int rdetr_msda_forward_f32(const float *value, const int64_t *spatial
                                       const float *attn_weight, int B, int S, int H, int D, int L, int Nq, int P,
                                       float *out, void *stream)
 {
-    return rdetr::msda_forward<float, false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr,
-                                             0, B, S, H, D, L, Nq, P, out, static_cast<hipStream_t>(stream));
+    return rdetr::msda_forward<float, false>(value, RDETR_VALUE_BSHD, spatial_shapes, level_start_index, sampling_loc,
+                                             attn_weight, nullptr, 0, B, S, H, D, L, Nq, P, out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rdetr_msda_forward_bf16(const uint16_t *value, const int64_t *spatial_shapes,
@@ -463,8 +469,9 @@ extern "C" int rdetr_msda_forward_bf16(const uint16_t *value, const int64_t *spa
                                        const float *attn_weight, int B, int S, int H, int D, int L, int Nq, int P,
                                        uint16_t *out, void *stream)
 {
-    return rdetr::msda_forward<uint16_t, false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                                nullptr, 0, B, S, H, D, L, Nq, P, out, static_cast<hipStream_t>(stream));
+    return rdetr::msda_forward<uint16_t, false>(value, RDETR_VALUE_BSHD, spatial_shapes, level_start_index, sampling_loc,
+                                                attn_weight, nullptr, 0, B, S, H, D, L, Nq, P, out,
+                                                static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rdetr_msda_forward_fused_f32(const float *value, const int64_t *spatial_shapes,
@@ -472,8 +479,8 @@ extern "C" int rdetr_msda_forward_fused_f32(const float *value, const int64_t *s
                                             const float *attn_logits, const float *reference_points, int ref_dim, int B,
                                             int S, int H, int D, int L, int Nq, int P, float *out, void *stream)
 {
-    return rdetr::msda_forward<float, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                            reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+    return rdetr::msda_forward<float, true>(value, RDETR_VALUE_BSHD, spatial_shapes, level_start_index, sampling_offsets,
+                                            attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
                                             static_cast<hipStream_t>(stream));
 }
 
@@ -482,173 +489,13 @@ extern "C" int rdetr_msda_forward_fused_bf16(const uint16_t *value, const int64_
                                              const uint16_t *attn_logits, const float *reference_points, int ref_dim,
                                              int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream)
 {
-    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                               reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+    return rdetr::msda_forward<uint16_t, true>(value, RDETR_VALUE_BSHD, spatial_shapes, level_start_index, sampling_offsets,
+                                               attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
                                                static_cast<hipStream_t>(stream));
 }
 
-// ---------------------------------------------------------------------------------------------
-// "Planned" entry points: same operators, plus a HOST copy of the shape table so that the launch can be planned
-// around the pyramid geometry.  RDETR_MSDA_ALGO selects the strategy (read once):
-//   qrun (default) -- the direct query-run kernel (the fastest of the four in round 1);
-//   hybrid         -- csrc/msda_hybrid.hip: planes of the coarsest levels resident in LDS (L == 4, Nq >= 1024);
-//   tile2d, sweep  -- encoder-shape (Nq == S) strategies: 2-D patch launch / LDS band kernel (csrc/msda_sweep.hip).
-// The three alternatives are experimental: correct (parity-tested) but not faster.
-namespace rdetr {
-template <typename T, bool FUSED>
-int msda_sweep_forward(const T *value, const int64_t *host_shapes, const void *src_a, const void *src_b, const float *ref,
-                       int ref_dim, int B, int S, int L, T *out, hipStream_t stream);
-template <typename T, bool FUSED>
-int msda_hybrid_forward(const T *value, const int64_t *shapes, const int64_t *level_start, const int64_t *host_shapes,
-                        const void *src_a, const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq,
-                        T *out, hipStream_t stream);
-
-template <typename T, bool FUSED>
-static int msda_planned(const T *value, const int64_t *shapes, const int64_t *level_start, const int64_t *host_shapes,
-                        const void *src_a, const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq,
-                        T *out, hipStream_t stream)
-{
-    if (!host_shapes) return RDETR_ERR_INVALID_ARG;
-    if (B < 0 || S < 0 || Nq < 0 || L <= 0) return RDETR_ERR_INVALID_ARG;
-    const char algo = msda_algo();
-    if (B > 0 && Nq > 0 && S > 0 && value && src_a && src_b && out && (!FUSED || ref)) {
-        if (algo == 's' && Nq == S) {
-            const int st = msda_sweep_forward<T, FUSED>(value, host_shapes, src_a, src_b, ref, ref_dim, B, S, L, out, stream);
-            if (st != RDETR_ERR_UNSUPPORTED) return st;
-        }
-        if (algo == 'h') {
-            const int st = msda_hybrid_forward<T, FUSED>(value, shapes, level_start, host_shapes, src_a, src_b, ref, ref_dim,
-                                                         B, S, L, Nq, out, stream);
-            if (st != RDETR_ERR_UNSUPPORTED) return st;
-        }
-    }
-    return msda_forward<T, FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, kHeads, kHeadDim, L, Nq,
-                                  kPoints, out, stream, (algo == 't' && Nq == S) ? host_shapes : nullptr);
-}
-}  // namespace rdetr
-
-extern "C" int rdetr_msda_forward_planned_f32(const float *value, const int64_t *spatial_shapes,
-                                              const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                              const float *sampling_loc, const float *attn_weight, int B, int S, int L,
-                                              int Nq, float *out, void *stream)
-{
-    return rdetr::msda_planned<float, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
-                                             attn_weight, nullptr, 0, B, S, L, Nq, out, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int rdetr_msda_forward_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                               const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                               const float *sampling_loc, const float *attn_weight, int B, int S, int L,
-                                               int Nq, uint16_t *out, void *stream)
-{
-    return rdetr::msda_planned<uint16_t, false>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc,
-                                                attn_weight, nullptr, 0, B, S, L, Nq, out,
-                                                static_cast<hipStream_t>(stream));
-}
-
-extern "C" int rdetr_msda_forward_fused_planned_f32(const float *value, const int64_t *spatial_shapes,
-                                                    const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                                    const float *sampling_offsets, const float *attn_logits,
-                                                    const float *reference_points, int ref_dim, int B, int S, int L,
-                                                    int Nq, float *out, void *stream)
-{
-    return rdetr::msda_planned<float, true>(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_offsets,
-                                            attn_logits, reference_points, ref_dim, B, S, L, Nq, out,
-                                            static_cast<hipStream_t>(stream));
-}
-
-extern "C" int rdetr_msda_forward_fused_planned_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                                     const int64_t *level_start_index, const int64_t *host_spatial_shapes,
-                                                     const uint16_t *sampling_offsets, const uint16_t *attn_logits,
-                                                     const float *reference_points, int ref_dim, int B, int S, int L,
-                                                     int Nq, uint16_t *out, void *stream)
-{
-    return rdetr::msda_planned<uint16_t, true>(value, spatial_shapes, level_start_index, host_spatial_shapes,
-                                               sampling_offsets, attn_logits, reference_points, ref_dim, B, S, L, Nq, out,
-                                               static_cast<hipStream_t>(stream));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Explicit-strategy entry points (A/B measurement, tests).
-namespace rdetr {
-template <bool FUSED>
-static int msda_tiled_entry(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
-                            const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, uint16_t *out,
-                            hipStream_t stream)
-{
-    if (B < 0 || S < 0 || Nq < 0 || L <= 0) return RDETR_ERR_INVALID_ARG;
-    if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
-    if (B == 0 || Nq == 0) return RDETR_OK;
-    if (!value || !shapes || !level_start || !src_a || !src_b || !out || (FUSED && !ref)) return RDETR_ERR_INVALID_ARG;
-    auto al = [](const void *p, unsigned a) { return reinterpret_cast<uintptr_t>(p) % a == 0; };
-    if (!al(value, 16) || !al(out, 16) || !al(src_a, 8) || !al(src_b, 4)) return RDETR_ERR_UNSUPPORTED;
-    return msda_tile_forward<FUSED>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S, L, Nq, out, stream);
-}
-}  // namespace rdetr
-
-extern "C" int rdetr_msda_forward_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                             const int64_t *level_start_index, const float *sampling_loc,
-                                             const float *attn_weight, int B, int S, int L, int Nq, uint16_t *out,
-                                             void *stream)
-{
-    return rdetr::msda_tiled_entry<false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, 0,
-                                          B, S, L, Nq, out, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int rdetr_msda_forward_fused_tiled_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                                   const int64_t *level_start_index, const uint16_t *sampling_offsets,
-                                                   const uint16_t *attn_logits, const float *reference_points,
-                                                   int ref_dim, int B, int S, int L, int Nq, uint16_t *out, void *stream)
-{
-    return rdetr::msda_tiled_entry<true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                         reference_points, ref_dim, B, S, L, Nq, out, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int rdetr_msda_forward_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                              const int64_t *level_start_index, const float *sampling_loc,
-                                              const float *attn_weight, int B, int S, int L, int Nq, uint16_t *out,
-                                              void *stream)
-{
-    return rdetr::msda_forward<uint16_t, false>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                                nullptr, 0, B, S, rdetr::kHeads, rdetr::kHeadDim, L, Nq, rdetr::kPoints,
-                                                out, static_cast<hipStream_t>(stream), nullptr, true);
-}
-
-extern "C" int rdetr_msda_forward_fused_direct_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                                    const int64_t *level_start_index, const uint16_t *sampling_offsets,
-                                                    const uint16_t *attn_logits, const float *reference_points,
-                                                    int ref_dim, int B, int S, int L, int Nq, uint16_t *out, void *stream)
-{
-    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                               reference_points, ref_dim, B, S, rdetr::kHeads, rdetr::kHeadDim, L, Nq,
-                                               rdetr::kPoints, out, static_cast<hipStream_t>(stream), nullptr, true);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused-producer form with the padding mask applied inside the gather (no fill pass over the projected value).
-extern "C" int rdetr_msda_forward_fused_masked_f32(const float *value, const int64_t *spatial_shapes,
-                                                   const int64_t *level_start_index, const float *sampling_offsets,
-                                                   const float *attn_logits, const float *reference_points, int ref_dim,
-                                                   const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq,
-                                                   int P, float *out, void *stream)
-{
-    return rdetr::msda_forward<float, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                            reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
-                                            static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask);
-}
-
-extern "C" int rdetr_msda_forward_fused_masked_bf16(const uint16_t *value, const int64_t *spatial_shapes,
-                                                    const int64_t *level_start_index, const uint16_t *sampling_offsets,
-                                                    const uint16_t *attn_logits, const float *reference_points, int ref_dim,
-                                                    const uint8_t *key_padding_mask, int B, int S, int H, int D, int L,
-                                                    int Nq, int P, uint16_t *out, void *stream)
-{
-    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                               reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
-                                               static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask);
-}
-
-// Fused-producer form, general: optional padding mask and row strides of the two projection outputs.
+// Fused-producer form, general: optional padding mask (applied inside the gather: no fill pass over the projected value) and
+// row strides of the two projection outputs.
 extern "C" int rdetr_msda_forward_fused_ex_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
                                                const float *sampling_offsets, int ld_offsets, const float *attn_logits,
                                                int ld_logits, const float *reference_points, int ref_dim,
@@ -658,9 +505,10 @@ extern "C" int rdetr_msda_forward_fused_ex_f32(const float *value, const int64_t
     if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
         ld_offsets % 2 != 0)
         return RDETR_ERR_INVALID_ARG;
-    return rdetr::msda_forward<float, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                            reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
-                                            static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask, ld_offsets, ld_logits);
+    return rdetr::msda_forward<float, true>(value, RDETR_VALUE_BSHD, spatial_shapes, level_start_index, sampling_offsets,
+                                            attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                            static_cast<hipStream_t>(stream), RDETR_MSDA_AUTO, key_padding_mask, ld_offsets,
+                                            ld_logits);
 }
 
 extern "C" int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spatial_shapes,
@@ -672,8 +520,47 @@ extern "C" int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int
     if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
         ld_offsets % 2 != 0)
         return RDETR_ERR_INVALID_ARG;
-    return rdetr::msda_forward<uint16_t, true>(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                               reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
-                                               static_cast<hipStream_t>(stream), nullptr, true, key_padding_mask, ld_offsets,
+    return rdetr::msda_forward<uint16_t, true>(value, RDETR_VALUE_BSHD, spatial_shapes, level_start_index, sampling_offsets,
+                                               attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                               static_cast<hipStream_t>(stream), RDETR_MSDA_AUTO, key_padding_mask, ld_offsets,
                                                ld_logits);
+}
+
+// bf16 operator with the value layout and the kernel choice as explicit arguments (tests, A/B timing, and the module path,
+// whose value projection writes the head-major layout).
+extern "C" int rdetr_msda_forward_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
+                                           const int64_t *level_start_index, const float *sampling_loc,
+                                           const float *attn_weight, int B, int S, int H, int D, int L, int Nq, int P,
+                                           int algo, uint16_t *out, void *stream)
+{
+    return rdetr::msda_forward<uint16_t, false>(value, value_layout, spatial_shapes, level_start_index, sampling_loc,
+                                                attn_weight, nullptr, 0, B, S, H, D, L, Nq, P, out,
+                                                static_cast<hipStream_t>(stream), algo);
+}
+
+extern "C" int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
+                                                 const int64_t *level_start_index, const uint16_t *sampling_offsets,
+                                                 int ld_offsets, const uint16_t *attn_logits, int ld_logits,
+                                                 const float *reference_points, int ref_dim, const uint8_t *key_padding_mask,
+                                                 int B, int S, int H, int D, int L, int Nq, int P, int algo, uint16_t *out,
+                                                 void *stream)
+{
+    if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
+        ld_offsets % 2 != 0)
+        return RDETR_ERR_INVALID_ARG;
+    return rdetr::msda_forward<uint16_t, true>(value, value_layout, spatial_shapes, level_start_index, sampling_offsets,
+                                               attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                               static_cast<hipStream_t>(stream), algo, key_padding_mask, ld_offsets, ld_logits);
+}
+
+extern "C" int rdetr_value_to_head_major_bf16(const uint16_t *src, long long ld, const uint8_t *key_padding_mask, int B, int S,
+                                              int H, int D, uint16_t *dst, void *stream)
+{
+    if (B < 0 || S < 0 || H != rdetr::kHeads || D != rdetr::kHeadDim || ld < H * D || ld % 8) return RDETR_ERR_INVALID_ARG;
+    if (B == 0 || S == 0) return RDETR_OK;
+    if (!src || !dst || reinterpret_cast<uintptr_t>(src) % 16 || reinterpret_cast<uintptr_t>(dst) % 16) return RDETR_ERR_INVALID_ARG;
+    if (B > 65535) return RDETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(rdetr::value_to_head_major_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, ld, key_padding_mask, S, dst);
+    return rdetr::launch_status();
 }

@@ -25,12 +25,35 @@ def image_block(num_images: int, rank: int, world_size: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def gather_detections(dets: torch.Tensor, image_ids: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+def pad_block(dets: torch.Tensor, image_ids: torch.Tensor, b_local: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pad a rank's block to ``b_local`` images (image id -1, zero detections) so that every rank contributes the same
+    shape to the fixed-shape all-gather; ``image_block`` sizes differ by at most one."""
+    n = dets.shape[0]
+    if n > b_local:
+        raise ValueError(f"block of {n} images does not fit B_local = {b_local}")
+    if n == b_local:
+        return dets, image_ids
+    pad_d = dets.new_zeros((b_local - n,) + tuple(dets.shape[1:]))
+    pad_i = image_ids.new_full((b_local - n,), -1)
+    return torch.cat([dets, pad_d], 0), torch.cat([image_ids, pad_i], 0)
+
+
+def gather_detections(dets: torch.Tensor, image_ids: torch.Tensor, group=None, check_equal: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather ``dets [B_local, K, 6]`` and ``image_ids [B_local]`` from every rank (equal
     B_local on all ranks) -> ``([world*B_local, K, 6], [world*B_local])`` ordered by rank."""
     if not (dist.is_available() and dist.is_initialized()):
         return dets, image_ids
     world = dist.get_world_size(group)
+    if dets.shape[0] != image_ids.shape[0]:
+        raise ValueError("gather_detections: dets and image_ids disagree on B_local")
+    # a fixed-shape all-gather hangs or corrupts data on unequal inputs (image_block sizes may differ by one): agree on
+    # B_local first -- one tiny all-reduce, only when the check is asked for (the bench's equal blocks skip it)
+    if check_equal:
+        probe = torch.tensor([dets.shape[0], -dets.shape[0]], device=dets.device, dtype=torch.int64)
+        dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+        if int(probe[0]) != -int(probe[1]):
+            raise ValueError(f"gather_detections: ranks hold between {-int(probe[1])} and {int(probe[0])} images; pad every "
+                             f"rank's block to the same B_local (dist.pad_block) before the gather")
     dets = dets.contiguous()
     image_ids = image_ids.contiguous()
     out_d = dets.new_empty((world * dets.shape[0],) + tuple(dets.shape[1:]))

@@ -152,12 +152,21 @@ class MultiScaleDeformableAttention(nn.Module):
         _force = os.environ.get("RDETR_MASK_IN_KERNEL")          # A/B aid: "always" / "never"
         if _force and fused and key_padding_mask is not None:
             mask_in_kernel = _force == "always"
-        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not mask_in_kernel,
+        # encoder shape (queries = the pyramid's own pixels) in bf16: the LDS-window kernel (csrc/msda_win.hip) serves it, and it
+        # fills its windows fastest from a head-major value [B,H,S,D] -- so the projected value is re-laid out once per call,
+        # with the padding zero-fill folded into that pass (no fill pass of its own)
+        head_major = (fused and value.dtype == torch.bfloat16 and query.shape[1] == value.shape[1] and self.num_levels == 4
+                      and value.shape[1] >= 4096 and os.environ.get("RDETR_VALUE_HEAD_MAJOR", "1") != "0")
+        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not (mask_in_kernel or head_major),
                                               merged=fused and os.environ.get("RDETR_MERGED_PROJ", "1") != "0")
         core_dtype = v.dtype if v.dtype in (torch.float32, torch.bfloat16) else torch.float32
         needs_grad = torch.is_grad_enabled() and any(
             t.requires_grad for t in (v, offsets, logits, reference_points))
-        if fused:
+        if fused and head_major and v.dtype == torch.bfloat16:
+            vh = ops.value_to_head_major(v.view(v.shape[0], v.shape[1], -1), key_padding_mask)
+            core = ops.ms_deform_attn_forward_fused(vh, spatial_shapes, level_start_index, offsets, logits,
+                                                    reference_points.float().contiguous(), None, value_layout="bhsd")
+        elif fused:
             # inference: softmax + location arithmetic happen inside the gather kernel's set-up phase, and so does the
             # padding mask (rows of padded positions count as zero: no fill pass over the projected value)
             core = ops.ms_deform_attn_forward_fused(

@@ -9,8 +9,6 @@ No CPU path: a tensor that is not on a ROCm device raises, and so does a missing
 """
 from __future__ import annotations
 
-import ctypes
-import os
 import weakref
 from typing import Optional, Tuple
 
@@ -73,35 +71,34 @@ def check_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, 
                 f"level (h={h}, w={w}, start={s}) does not fit a value tensor with {num_value} positions")
 
 
-def _host_shape_table(spatial_shapes, level_start_index, S, H, D, L, P):
-    """Host copy of the [L,2] shape table as a ctypes int64 array when the planned entry points apply -- H = 8,
-    D = 32, P = 4, L <= 8, levels packed contiguously and covering the value tensor -- else None.
-    The planned entry points only differ from the plain ones when an experimental strategy is selected
-    (RDETR_MSDA_ALGO=hybrid|tile2d|sweep), so without that variable the plain entry points are used."""
-    if (H, D, P) != (8, 32, 4) or L > 8 or os.environ.get("RDETR_MSDA_ALGO", "qrun") not in ("hybrid", "tile2d", "sweep"):
-        return None
-    shapes, starts = host_levels(spatial_shapes, level_start_index)
-    run = 0
-    for (h, w), st in zip(shapes, starts):
-        if st != run:
-            return None
-        run += h * w
-    if run != S:
-        return None
-    flat = [v for hw in shapes for v in hw]
-    return (ctypes.c_int64 * len(flat))(*flat)
+VALUE_BSHD, VALUE_BHSD = 0, 1                     # include/relation_detr_amd.h: RDETR_VALUE_*
+MSDA_AUTO, MSDA_DIRECT, MSDA_WINDOW = 0, 1, 2     # RDETR_MSDA_*
+_ALGO = {"auto": MSDA_AUTO, "direct": MSDA_DIRECT, "window": MSDA_WINDOW}
+
+
+def _value_dims(value: torch.Tensor, layout: str):
+    """(B, S, H, D) of a value tensor in layout "bshd" ([B,S,H,D], the reference operator's) or "bhsd" (head-major)."""
+    if value.dim() != 4 or layout not in ("bshd", "bhsd"):
+        raise _lib.RdetrError("expected a 4-d value tensor in layout 'bshd' or 'bhsd'")
+    if layout == "bshd":
+        return tuple(value.shape)
+    B, H, S, D = value.shape
+    return B, S, H, D
 
 
 def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
-                           sampling_loc: torch.Tensor, attn_weight: torch.Tensor, im2col_step: int = 64) -> torch.Tensor:
+                           sampling_loc: torch.Tensor, attn_weight: torch.Tensor, im2col_step: int = 64,
+                           value_layout: str = "bshd", algo: str = "auto") -> torch.Tensor:
     """value [B,S,H,D] (fp32 or bf16), sampling_loc [B,Nq,H,L,P,2] fp32, attn_weight [B,Nq,H,L,P] fp32
-    -> [B,Nq,H*D] in value's dtype.  ``im2col_step`` is accepted and ignored (no batch restriction)."""
+    -> [B,Nq,H*D] in value's dtype.  ``im2col_step`` is accepted and ignored (no batch restriction).
+    Not in the reference's signature (optional, bf16 only): ``value_layout="bhsd"`` for a head-major value [B,H,S,D]
+    (`value_to_head_major`), ``algo`` "auto" | "direct" | "window" to name the kernel (tests, A/B timing)."""
     _require_device(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                         sampling_loc=sampling_loc, attn_weight=attn_weight)
     if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
         raise _lib.RdetrError("expected value [B,S,H,D], sampling_loc [B,Nq,H,L,P,2], attn_weight [B,Nq,H,L,P]")
-    B, S, H, D = value.shape
+    B, S, H, D = _value_dims(value, value_layout)
     _, Nq, H2, L, P, two = sampling_loc.shape
     if (H2, two) != (H, 2) or tuple(attn_weight.shape) != (B, Nq, H, L, P) or sampling_loc.shape[0] != B:
         raise _lib.RdetrError("sampling_loc / attn_weight shapes do not match value")
@@ -109,25 +106,53 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_loc")
     if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
         raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
+    if algo not in _ALGO:
+        raise ValueError("algo must be 'auto', 'direct' or 'window'")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if value.dtype == torch.bfloat16 and (value_layout != "bshd" or algo != "auto"):
+        st = lib.rdetr_msda_forward_opt_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD,
+                                             spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                                             attn_weight.data_ptr(), B, S, H, D, L, Nq, P, _ALGO[algo], out.data_ptr(),
+                                             _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_opt_bf16")
+        return out
+    if value_layout != "bshd" or algo != "auto":
+        raise _lib.RdetrError("value_layout / algo options exist for bfloat16 value only")
     if value.dtype == torch.float32:
         fn = lib.rdetr_msda_forward_f32
     elif value.dtype == torch.bfloat16:
         fn = lib.rdetr_msda_forward_bf16
     else:
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
-    host = _host_shape_table(spatial_shapes, level_start_index, S, H, D, L, P)
-    if host is not None:            # launch planned around the pyramid geometry (hybrid LDS / direct kernel)
-        planned = lib.rdetr_msda_forward_planned_f32 if value.dtype == torch.float32 else lib.rdetr_msda_forward_planned_bf16
-        st = planned(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), host,
-                     sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, L, Nq, out.data_ptr(), _stream_ptr(value))
-        _lib.check(st, "rdetr_msda_forward_planned")
-        return out
     st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
     _lib.check(st, "rdetr_msda_forward")
+    return out
+
+
+def value_to_head_major(value: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Projected value [B,S,256] bf16 (rows may be a column slice of a wider buffer) -> head-major [B,8,S,32], the rows of
+    padded positions zeroed on the way (ms_deform_attn.py:316-319): the layout the window kernel fills its LDS windows
+    from at the contiguous-row rate (pass the result with ``value_layout="bhsd"``)."""
+    _require_device(value, key_padding_mask)
+    if value.dim() != 3 or value.shape[-1] != 256 or value.dtype != torch.bfloat16:
+        raise _lib.RdetrError("value_to_head_major: expected a bfloat16 [B, S, 256] tensor")
+    B, S, _ = value.shape
+    if value.stride(2) != 1 or (B > 1 and value.stride(0) != S * value.stride(1)) or value.stride(1) % 8 or value.data_ptr() % 16:
+        value = value.contiguous()
+    mask_ptr = None
+    if key_padding_mask is not None:
+        if tuple(key_padding_mask.shape) != (B, S):
+            raise _lib.RdetrError("key_padding_mask must be [B, S]")
+        mask_u8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool \
+            else key_padding_mask.to(torch.uint8).contiguous()
+        mask_ptr = mask_u8.data_ptr()
+    out = torch.empty(B, 8, S, 32, dtype=torch.bfloat16, device=value.device)
+    st = _lib.load().rdetr_value_to_head_major_bf16(value.data_ptr(), value.stride(1), mask_ptr, B, S, 8, 32, out.data_ptr(),
+                                                    _stream_ptr(value))
+    _lib.check(st, "rdetr_value_to_head_major_bf16")
     return out
 
 
@@ -149,12 +174,15 @@ def _producer_row_stride(t: torch.Tensor):
 
 def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
                                  sampling_offsets: torch.Tensor, attn_logits: torch.Tensor,
-                                 reference_points: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                                 reference_points: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None,
+                                 value_layout: str = "bshd", algo: str = "auto") -> torch.Tensor:
     """MSDA with the location / weight producer fused into the gather kernel (inference path).
-    value [B,S,H,D] fp32|bf16; sampling_offsets [B,Nq,H,L,P,2] and attn_logits [B,Nq,H,L*P] RAW projection
-    outputs in value's dtype; reference_points [B,Nq,L,2|4] fp32 -> [B,Nq,H*D] in value's dtype.
+    value [B,S,H,D] fp32|bf16 (or head-major [B,H,S,D] bf16 with ``value_layout="bhsd"``); sampling_offsets
+    [B,Nq,H,L,P,2] and attn_logits [B,Nq,H,L*P] RAW projection outputs in value's dtype; reference_points [B,Nq,L,2|4] fp32
+    -> [B,Nq,H*D] in value's dtype.  ``key_padding_mask`` [B,S]: `value` is then the UNFILLED projection and the kernel treats
+    the rows of padded positions as zero.
     Same result as softmax + sampling-location arithmetic + ms_deform_attn_forward (ms_deform_attn.py:322-370)."""
-    _require_device(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points)
+    _require_device(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points, key_padding_mask)
     # the two projection outputs may be column slices of one wider GEMM output (rows evenly strided, each row contiguous)
     ld_off = _producer_row_stride(sampling_offsets)
     ld_lg = _producer_row_stride(attn_logits)
@@ -166,7 +194,7 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
                         reference_points=reference_points)
     if value.dim() != 4 or sampling_offsets.dim() != 6 or reference_points.dim() != 4:
         raise _lib.RdetrError("expected value [B,S,H,D], sampling_offsets [B,Nq,H,L,P,2], reference_points [B,Nq,L,2|4]")
-    B, S, H, D = value.shape
+    B, S, H, D = _value_dims(value, value_layout)
     _, Nq, H2, L, P, two = sampling_offsets.shape
     ref_dim = reference_points.shape[-1]
     if (H2, two) != (H, 2) or sampling_offsets.shape[0] != B or attn_logits.numel() != B * Nq * H * L * P:
@@ -177,94 +205,40 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         raise _lib.RdetrError("sampling_offsets / attn_logits must have value's dtype, reference_points float32")
     if spatial_shapes.shape[0] != L:
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_offsets")
+    if algo not in _ALGO:
+        raise ValueError("algo must be 'auto', 'direct' or 'window'")
+    if value.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
+    if value.dtype == torch.float32 and (value_layout != "bshd" or algo != "auto"):
+        raise _lib.RdetrError("value_layout / algo options exist for bfloat16 value only")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
-    if value.dtype == torch.float32:
-        fn = lib.rdetr_msda_forward_fused_f32
-    elif value.dtype == torch.bfloat16:
-        fn = lib.rdetr_msda_forward_fused_bf16
-    else:
-        raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
-    out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
-    if ld_off or ld_lg:                 # strided producer rows (merged projection), optional padding mask
-        mask_ptr = None
-        if key_padding_mask is not None:
-            _require_device(key_padding_mask)
-            if tuple(key_padding_mask.shape) != (B, S):
-                raise _lib.RdetrError("key_padding_mask must be [B, S]")
-            mask_u8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool \
-                else key_padding_mask.to(torch.uint8).contiguous()
-            mask_ptr = mask_u8.data_ptr()
-        fx = lib.rdetr_msda_forward_fused_ex_f32 if value.dtype == torch.float32 else lib.rdetr_msda_forward_fused_ex_bf16
-        st = fx(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(), ld_off,
-                attn_logits.data_ptr(), ld_lg, reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P,
-                out.data_ptr(), _stream_ptr(value))
-        _lib.check(st, "rdetr_msda_forward_fused_ex")
-        return out
+    mask_ptr = None
     if key_padding_mask is not None:
-        # `value` is the UNFILLED projection: the kernel treats the rows of padded positions as zero (bool [B, S], True = padded)
-        _require_device(key_padding_mask)
         if tuple(key_padding_mask.shape) != (B, S):
             raise _lib.RdetrError("key_padding_mask must be [B, S]")
         mask_u8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool \
             else key_padding_mask.to(torch.uint8).contiguous()
-        fm = lib.rdetr_msda_forward_fused_masked_f32 if value.dtype == torch.float32 else lib.rdetr_msda_forward_fused_masked_bf16
-        st = fm(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
-                attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, mask_u8.data_ptr(), B, S, H, D, L, Nq, P,
-                out.data_ptr(), _stream_ptr(value))
-        _lib.check(st, "rdetr_msda_forward_fused_masked")
-        return out
-    host = _host_shape_table(spatial_shapes, level_start_index, S, H, D, L, P)
-    if host is not None:            # launch planned around the pyramid geometry (hybrid LDS / direct kernel)
-        planned = (lib.rdetr_msda_forward_fused_planned_f32 if value.dtype == torch.float32
-                   else lib.rdetr_msda_forward_fused_planned_bf16)
-        st = planned(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), host,
-                     sampling_offsets.data_ptr(), attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, B, S, L,
-                     Nq, out.data_ptr(), _stream_ptr(value))
-        _lib.check(st, "rdetr_msda_forward_fused_planned")
-        return out
-    st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
-            attn_logits.data_ptr(), reference_points.data_ptr(), ref_dim, B, S, H, D, L, Nq, P, out.data_ptr(),
-            _stream_ptr(value))
-    _lib.check(st, "rdetr_msda_forward_fused")
-    return out
-
-
-def ms_deform_attn_forward_strategy(strategy: str, value: torch.Tensor, spatial_shapes: torch.Tensor,
-                                    level_start_index: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
-                                    reference_points: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bf16 MSDA through ONE named kernel (A/B measurement, tests): strategy "tiled" (csrc/msda_tile.hip, encoder
-    shape only -- raises RdetrError "unsupported" otherwise) or "direct" (csrc/msda_fwd.hip).  With
-    ``reference_points`` None, (a, b) = (sampling_loc, attn_weight) fp32 as in ms_deform_attn_forward; else
-    (a, b) = raw (sampling_offsets, attn_logits) bf16 as in ms_deform_attn_forward_fused."""
-    if strategy not in ("tiled", "direct"):
-        raise ValueError("strategy must be 'tiled' or 'direct'")
-    fused = reference_points is not None
-    _require_device(value, spatial_shapes, level_start_index, a, b, reference_points)
-    _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index, a=a, b=b,
-                        reference_points=reference_points)
-    B, S, H, D = value.shape
-    _, Nq, H2, L, P, two = a.shape
-    if value.dtype != torch.bfloat16 or (H, D, P, H2, two) != (8, 32, 4, 8, 2) or a.shape[0] != B:
-        raise _lib.RdetrError("strategy entry points serve bf16 value with H = 8, D = 32, P = 4")
-    want = torch.bfloat16 if fused else torch.float32
-    if a.dtype != want or b.dtype != want or b.numel() != B * Nq * H * L * P:
-        raise _lib.RdetrError("sampling tensors have the wrong dtype or shape")
-    if fused and (reference_points.dtype != torch.float32 or tuple(reference_points.shape[:3]) != (B, Nq, L)
-                  or reference_points.shape[-1] not in (2, 4)):
-        raise _lib.RdetrError("reference_points must be float32 [B, Nq, L, 2|4]")
-    check_levels(spatial_shapes, level_start_index, S)
-    lib = _lib.load()
+        mask_ptr = mask_u8.data_ptr()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
-    if fused:
-        fn = getattr(lib, f"rdetr_msda_forward_fused_{strategy}_bf16")
-        st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
-                reference_points.data_ptr(), reference_points.shape[-1], B, S, L, Nq, out.data_ptr(), _stream_ptr(value))
-    else:
-        fn = getattr(lib, f"rdetr_msda_forward_{strategy}_bf16")
-        st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
-                B, S, L, Nq, out.data_ptr(), _stream_ptr(value))
-    _lib.check(st, f"rdetr_msda_forward_{strategy}")
+    if value.dtype == torch.bfloat16:
+        st = lib.rdetr_msda_forward_fused_opt_bf16(
+            value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_offsets.data_ptr(), ld_off, attn_logits.data_ptr(), ld_lg,
+            reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P, _ALGO[algo], out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_fused_opt_bf16")
+        return out
+    if ld_off or ld_lg or mask_ptr is not None:
+        st = lib.rdetr_msda_forward_fused_ex_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                                 sampling_offsets.data_ptr(), ld_off, attn_logits.data_ptr(), ld_lg,
+                                                 reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P,
+                                                 out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_fused_ex_f32")
+        return out
+    st = lib.rdetr_msda_forward_fused_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                          sampling_offsets.data_ptr(), attn_logits.data_ptr(), reference_points.data_ptr(),
+                                          ref_dim, B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
+    _lib.check(st, "rdetr_msda_forward_fused_f32")
     return out
 
 
@@ -613,15 +587,43 @@ def ffn_k256_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> b
             and F <= 4096 and w2.is_contiguous() and w2.data_ptr() % 16 == 0)
 
 
-_FFN_PACKED = {}        # (w1 ptr, w2 ptr) -> (versions, packed): the fragment-order copy of a layer's two weight matrices
+class _PackedWeightCache:
+    """Packed (fragment-order) copies of weight tensors, tied to the tensor OBJECTS: an entry holds weak references to its
+    source tensors and is only a hit while every reference still resolves to the very tensor passed in and the versions
+    match.  A freed model whose storage address is recycled by the caching allocator for another model's weights (same
+    `data_ptr()`, same `_version` after an identical build sequence) can therefore never alias a stale packed copy --
+    the pattern `host_levels` uses for the shape tables."""
+
+    def __init__(self, limit: int = 64):
+        self._entries: dict = {}
+        self._limit = limit
+
+    def get(self, tensors, build):
+        key = tuple(id(t) for t in tensors)
+        ver = tuple((t._version, tuple(t.shape), t.data_ptr(), t.device) for t in tensors)
+        hit = self._entries.get(key)
+        if hit is not None:
+            refs, hver, packed = hit
+            if hver == ver and all(r() is t for r, t in zip(refs, tensors)):
+                return packed
+        if len(self._entries) >= self._limit:           # drop entries whose tensors are gone, then (rarely) everything
+            self._entries = {k: v for k, v in self._entries.items() if all(r() is not None for r in v[0])}
+            if len(self._entries) >= self._limit:
+                self._entries.clear()
+        packed = build()
+        self._entries[key] = (tuple(weakref.ref(t) for t in tensors), ver, packed)
+        return packed
+
+    def __len__(self):
+        return len(self._entries)
+
+
+_FFN_PACKED = _PackedWeightCache()        # (w1, w2) -> the fragment-order copy of a layer's two weight matrices
 
 
 def ffn_k256_packed_weights(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-    """The (w1, w2) pair re-ordered for `ffn_k256` (rdetr_ffn_k256_pack_bf16); cached until either tensor changes."""
-    key = (w1.data_ptr(), w2.data_ptr(), w1.device)
-    ver = (w1._version, w2._version, tuple(w1.shape))
-    hit = _FFN_PACKED.get(key)
-    if hit is None or hit[0] != ver:
+    """The (w1, w2) pair re-ordered for `ffn_k256` (rdetr_ffn_k256_pack_bf16); cached until either tensor changes or dies."""
+    def build():
         F = w1.shape[0]
         packed = torch.empty(2 * 256 * F, dtype=torch.bfloat16, device=w1.device)
         st = _lib.load().rdetr_ffn_k256_pack_bf16(w1.data_ptr(), w2.data_ptr(), F, packed.data_ptr(), _stream_ptr(w1))
@@ -629,11 +631,8 @@ def ffn_k256_packed_weights(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
         if not torch.cuda.is_current_stream_capturing():
             # once per weight update: other streams (image groups) pick the cached tensor up without an event of their own
             torch.cuda.current_stream(w1.device).synchronize()
-        if len(_FFN_PACKED) > 64:
-            _FFN_PACKED.clear()
-        hit = (ver, packed)
-        _FFN_PACKED[key] = hit
-    return hit[1]
+        return packed
+    return _FFN_PACKED.get((w1, w2), build)
 
 
 def ffn_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
@@ -697,7 +696,7 @@ def ffn_ln_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.T
     return out if pos is None else (out, out2)
 
 
-_LINEAR_PACKED = {}     # weight ptr -> (version, packed)
+_LINEAR_PACKED = _PackedWeightCache()     # (weight,) -> fragment-order copy
 
 
 def linear_ln_k256_supported(x: torch.Tensor, weight: torch.Tensor, residual: torch.Tensor) -> bool:
@@ -731,18 +730,14 @@ def linear_ln_k256(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     if orows != rows or ldo % 8 or out.data_ptr() % 16:
         raise _lib.RdetrError("linear_ln_k256: out rows must be 16-byte aligned")
     lib = _lib.load()
-    key, ver = (weight.data_ptr(), weight.device), weight._version
-    hit = _LINEAR_PACKED.get(key)
-    if hit is None or hit[0] != ver:
+    def build():
         packed = torch.empty(256 * 256, dtype=torch.bfloat16, device=weight.device)
         _lib.check(lib.rdetr_linear_pack_k256_bf16(weight.data_ptr(), packed.data_ptr(), _stream_ptr(weight)), "rdetr_linear_pack_k256_bf16")
         if not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream(weight.device).synchronize()
-        if len(_LINEAR_PACKED) > 64:
-            _LINEAR_PACKED.clear()
-        hit = (ver, packed)
-        _LINEAR_PACKED[key] = hit
-    st = lib.rdetr_linear_ln_k256_bf16(x.data_ptr(), ldx, hit[1].data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
+        return packed
+    packed_w = _LINEAR_PACKED.get((weight,), build)
+    st = lib.rdetr_linear_ln_k256_bf16(x.data_ptr(), ldx, packed_w.data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
                                        residual.data_ptr(), ldr, gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(),
                                        float(eps), rows, out.data_ptr(), ldo, _stream_ptr(x))
     _lib.check(st, "rdetr_linear_ln_k256_bf16")

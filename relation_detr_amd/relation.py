@@ -40,16 +40,18 @@ class _RelationBiasFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, tgt, weight, bias, num_pos_feats, temperature, scale):
         out = ops.relation_bias(src, tgt, weight, bias, num_pos_feats, temperature, scale)
-        ctx.save_for_backward(src, tgt, out)
+        # the caller owns `out` and mutates it in place (`masked_fill_(attn_mask, -inf)`, relation_transformer.py:372-374;
+        # the reference returns a clone for the same reason, :530-532): save the ReLU mask, a tensor the caller cannot reach
+        ctx.save_for_backward(src, tgt, out > 0)
         ctx.cfg = (num_pos_feats, temperature, scale, weight.shape, bias is not None)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
-        src, tgt, out = ctx.saved_tensors
+        src, tgt, active = ctx.saved_tensors
         F_, temperature, scale, wshape, has_bias = ctx.cfg
-        g = grad_out * (out > 0)                                       # ReLU'
+        g = grad_out * active                                          # ReLU'
         gw = torch.zeros(wshape[0], 4 * F_, dtype=torch.float32, device=g.device)
         for b in range(src.shape[0]):                                  # one image at a time bounds the feature tensor
             feat = _sine_features(box_rel_encoding(src[b:b + 1].float(), tgt[b:b + 1].float()), F_, temperature, scale)

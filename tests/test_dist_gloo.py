@@ -58,6 +58,78 @@ def test_gather_is_identity_without_process_group():
     assert out_d is d and out_i is i
 
 
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_launcher_two_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it starts two fresh rank processes itself, and rank 0 prints
+    ONE line with n_gpus = 2 (here over gloo with the stand-in step: the launcher, the barrier-bracketed loop, the
+    per-step gather and the max-over-ranks reduction are the code the 8-GPU run uses; the hot path needs a GPU)."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--batch", "4"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    res = lines[0]
+    assert res["n_gpus"] == 2 and res["world_size_seen"] == 2 and res["dry_run"] is True and res["gather_ok"] is True
+    assert len(res["per_rank_step_ms"]) == 2 and res["value"] is None
+    assert res["metric"].startswith("images/sec @ 800") and "300 queries" in res["metric"]
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus N must agree with the ranks actually launched: a silent 1-GPU run labelled otherwise is refused."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
+                                {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert rc != 0 and not lines and "WORLD_SIZE" in err
+    rc, lines, err = _run_bench(["--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0"])
+    assert rc == 0 and lines[0]["n_gpus"] == 1 and lines[0]["gather_ok"] is True
+
+
+def _unequal_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from relation_detr_amd.dist import pad_block
+        b, e = image_block(7, rank, world)                        # 4 + 3 images: unequal blocks
+        ids = torch.arange(b, e)
+        dets = torch.stack([torch.full((5, 6), float(i)) for i in ids.tolist()])
+        try:
+            gather_detections(dets, ids, check_equal=True)
+            refused = False
+        except ValueError:
+            refused = True
+        d2, i2 = pad_block(dets, ids, 4)
+        all_d, all_i = gather_detections(d2, i2, check_equal=True)
+        keep = all_i >= 0
+        ok = all_i[keep].tolist() == list(range(7)) and all((all_d[keep][i] == float(i)).all().item() for i in range(7))
+        q.put((rank, refused, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_refuses_unequal_blocks_and_pads():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_unequal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] and r[2] for r in res), res
+
+
 @pytest.mark.gpu
 def test_gather_detections_rccl_single_rank():
     """The RCCL code path (all_gather_into_tensor on device tensors) with a one-rank process group: the 8-GPU run

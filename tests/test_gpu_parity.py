@@ -377,7 +377,7 @@ def test_msda_module_train_and_eval_paths_agree(rd, golden):
     np.testing.assert_allclose(eval_out.cpu().numpy(), g["out_dec"], rtol=0, atol=1e-4)
 
 
-# ------------------------------------------------------------------------------------------ encoder sweep kernel
+# ------------------------------------------------------------------------------------------ encoder shape
 def _pixel_refs(shapes):
     refs = []
     for h, w in shapes:
@@ -395,10 +395,10 @@ def _pixel_refs(shapes):
     ([(64, 96), (32, 48), (16, 24), (8, 12)], 2, 4.0, torch.bfloat16),
 ])
 def test_encoder_entry_matches_oracle_and_plain_entry(rd, shapes, B, spread_px, dtype, monkeypatch):
-    """Encoder-shape calls (Nq == S): the Python op (which goes through rdetr_msda_forward_planned_* when
-    RDETR_MSDA_ALGO selects an experimental strategy) must agree with the oracle and, to rounding, with the
-    reference-equivalent C entry point, whatever the offsets.  tests/test_gpu_sweep.py repeats this file's encoder
-    cases in child processes with RDETR_MSDA_ALGO=sweep / tile2d / hybrid."""
+    """Encoder-shape calls (Nq == S): the Python op must agree with the oracle and, to rounding, with the plain C entry
+    point called directly through ctypes, whatever the offsets and the pyramid (5 levels, 1 level, tiny levels).  Where the
+    LDS-window kernel applies (bf16, 4 levels, S >= 4096) both go through it; tests/test_gpu_window.py pins it against the
+    direct kernel case by case."""
     from oracle import c_oracle
     shp, start, S = pyramid(shapes)
     L = len(shapes)
@@ -409,8 +409,8 @@ def test_encoder_entry_matches_oracle_and_plain_entry(rd, shapes, B, spread_px, 
     loc = (_pixel_refs(shapes)[None, :, None, None, None, :] + off).contiguous()
     attn = torch.softmax(torch.randn(B, S, 8, L * 4, generator=g), -1).view(B, S, 8, L, 4)
     args = (value.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV), 64)
-    out = rd.ms_deform_attn_forward(*args).float().cpu().numpy()           # planned entry point (RDETR_MSDA_ALGO)
-    lib = rd._lib.load()                                                   # reference-equivalent entry point (direct kernel)
+    out = rd.ms_deform_attn_forward(*args).float().cpu().numpy()
+    lib = rd._lib.load()                                                   # the C ABI, called directly
     direct_t = torch.empty(B, S, 256, dtype=dtype, device=DEV)
     fn = lib.rdetr_msda_forward_f32 if dtype == torch.float32 else lib.rdetr_msda_forward_bf16
     assert fn(args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(), args[3].data_ptr(), args[4].data_ptr(), B, S, 8, 32,

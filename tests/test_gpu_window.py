@@ -1,8 +1,11 @@
-"""GPU parity tests of the LDS-tiled encoder-shape MSDA kernel (csrc/msda_tile.hip, bf16, Nq == S, L == 4), called
-through the C ABI (rdetr_msda_forward[_fused]_tiled_bf16) -- against the C oracle on bf16-rounded value and against the
-direct query-run kernel on the same inputs.  The kernel copies, per 16x16 query tile and level, the window of the value
-plane the tile samples into LDS; samples outside the window are fetched from global memory.  The cases below therefore
-sweep the offset spread from "everything inside the window" to "nothing inside" -- the result must not depend on it.
+"""GPU parity tests of the LDS-window encoder-shape MSDA kernel (csrc/msda_win.hip, bf16, Nq == S, L == 4), called
+through the C ABI (rdetr_msda_forward[_fused]_opt_bf16 with algo = RDETR_MSDA_WINDOW) in BOTH value layouts ([B,S,H,D], the
+reference operator's, and head-major [B,H,S,D] as rdetr_value_to_head_major_bf16 writes it) -- against the C oracle on
+bf16-rounded value and against the direct query-run kernel on the same inputs.  The kernel copies, per 16x12 query tile
+and level, a window of the value plane into LDS (pixels outside the level arrive as zeros through the range-checked
+DMA); samples outside the window are fetched from global memory into a patch.  The cases below therefore sweep the
+offset spread from "everything inside the window" to "nothing inside" -- the result must not depend on it -- and put
+samples on / beyond every border.
 
 Tolerance: |err| <= 2^-8 |ref| + 1e-3 vs the fp32 oracle (one bf16 output rounding, fp32 accumulation; the reference op
 has no bf16 -- SURVEY.md Appendix B item 12); vs the direct kernel 2^-7 |ref| + 1e-3 (two independently rounded outputs).
@@ -56,6 +59,11 @@ def _encoder_inputs(shapes, B, spread_px, seed, scatter=0.0, poison=False):
     return value, shp, start, loc.contiguous(), attn.contiguous(), S, L
 
 
+def _head_major(value):
+    """[B,S,8,32] -> [B,8,S,32] by torch (the layout under test, not the repack kernel)."""
+    return value.permute(0, 2, 1, 3).contiguous()
+
+
 def _check(out, ref, direct=None):
     assert np.isfinite(out).all()
     bad = np.abs(out - ref) > 2.0 ** -8 * np.abs(ref) + 1e-3
@@ -65,31 +73,52 @@ def _check(out, ref, direct=None):
 
 
 @pytest.mark.parametrize("shapes,B,spread_px,scatter,poison", [
-    (R50, 1, 3.0, 0.0, False),                                   # every sample inside its tile's window
+    (R50, 1, 3.0, 0.0, False),                                   # (nearly) every sample inside its tile's window
     (R50, 2, 4.0, 0.0, True),                                    # BASELINE spread (sigma up to 4 px) + NaN / border cases
-    (R50, 1, 30.0, 0.0, False),                                  # windows clipped: most fine-level samples come from global memory
+    (R50, 1, 30.0, 0.0, False),                                  # most fine-level samples come from global memory (> 4 per wave: extra steps)
     ([(64, 96), (32, 48), (16, 24), (8, 12)], 2, 4.0, 0.05, False),      # multiples of the tile; 5 % scattered queries
     ([(75, 61), (38, 31), (19, 16), (10, 8)], 3, 6.0, 0.0, True),        # ragged tiles on every level
     ([(70, 70), (35, 35), (18, 18), (9, 9)], 1, 2.0, 1.0, False),        # all queries scattered: no locality at all
+    ([(160, 24), (80, 12), (40, 6), (20, 3)], 2, 3.0, 0.02, True),        # levels narrower than a window: zero columns on both sides
 ])
-def test_tiled_matches_oracle_and_direct(ops, shapes, B, spread_px, scatter, poison):
+def test_window_matches_oracle_and_direct(ops, shapes, B, spread_px, scatter, poison):
     from oracle import c_oracle
     value, shp, start, loc, attn, S, L = _encoder_inputs(shapes, B, spread_px, seed=int(spread_px * 7) + B, scatter=scatter,
                                                          poison=poison)
-    dev = (value.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV))
-    out = ops.ms_deform_attn_forward_strategy("tiled", *dev).float().cpu().numpy()
-    direct = ops.ms_deform_attn_forward_strategy("direct", *dev).float().cpu().numpy()
+    rest = (shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV))
+    v = value.to(DEV)
     ref = c_oracle.msda_forward(value.float().numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
+    direct = ops.ms_deform_attn_forward(v, *rest, algo="direct").float().cpu().numpy()
+    out = ops.ms_deform_attn_forward(v, *rest, algo="window").float().cpu().numpy()
     _check(out, ref, direct)
-    # the plain operator (direct kernel unless RDETR_MSDA_ALGO=lds) agrees with the explicit direct entry point bit for bit
-    auto = ops.ms_deform_attn_forward(*dev, 64).float().cpu().numpy()
+    # head-major value: both kernels
+    vh = _head_major(v)
+    out_h = ops.ms_deform_attn_forward(vh, *rest, value_layout="bhsd", algo="window").float().cpu().numpy()
+    assert np.array_equal(out_h, out)                     # same arithmetic, only the fill addresses differ
+    direct_h = ops.ms_deform_attn_forward(vh, *rest, value_layout="bhsd", algo="direct").float().cpu().numpy()
+    assert np.array_equal(direct_h, direct)
+    # the plain operator picks one of the two
+    auto = ops.ms_deform_attn_forward(v, *rest, 64).float().cpu().numpy()
     assert np.array_equal(auto, direct) or np.array_equal(auto, out)
 
 
-@pytest.mark.parametrize("ref_dim", [2, 4])
-def test_tiled_fused_producer(ops, ref_dim):
+def test_value_to_head_major(ops):
+    g = torch.Generator().manual_seed(3)
+    B, S = 3, 1000 + 37
+    wide = torch.randn(B, S, 3 * 256, generator=g).to(torch.bfloat16).to(DEV)
+    v = wide[..., 256:512]                                                   # a column slice: strided rows
+    mask = (torch.rand(B, S, generator=g) < 0.2).to(DEV)
+    got = ops.value_to_head_major(v, mask)
+    want = v.masked_fill(mask[..., None], 0).view(B, S, 8, 32).permute(0, 2, 1, 3)
+    assert got.shape == (B, 8, S, 32) and torch.equal(got, want)
+    assert torch.equal(ops.value_to_head_major(v.contiguous()), v.reshape(B, S, 8, 32).permute(0, 2, 1, 3))
+
+
+@pytest.mark.parametrize("ref_dim,strided", [(2, False), (4, False), (2, True)])
+def test_window_fused_producer(ops, ref_dim, strided):
     """raw offsets / logits + reference points in, softmax and location arithmetic inside the kernel
-    (ms_deform_attn.py:326-349): against the oracle's materialised sequence."""
+    (ms_deform_attn.py:326-349): against the oracle's materialised sequence; `strided`: the two producer tensors are
+    column slices of one [rows, 384] projection output, as the module passes them."""
     from oracle import torch_ref
     shapes = [(72, 100), (36, 50), (18, 25), (9, 13)]
     shp, start, S = pyramid(shapes)
@@ -102,35 +131,47 @@ def test_tiled_fused_producer(ops, ref_dim):
     if ref_dim == 4:
         ref = torch.cat([ref, torch.rand(B, S, L, 2, generator=g) * 0.2 + 0.02], -1)
     ref = ref.contiguous()
-    dev = (value.to(DEV), shp.to(DEV), start.to(DEV), off.to(DEV), logits.to(DEV), ref.to(DEV))
-    out = ops.ms_deform_attn_forward_strategy("tiled", *dev).float().cpu().numpy()
-    direct = ops.ms_deform_attn_forward_strategy("direct", *dev).float().cpu().numpy()
+    off_d, lg_d = off.to(DEV), logits.to(DEV)
+    if strided:
+        both = torch.cat([off_d.view(B, S, 256), lg_d.view(B, S, 128)], -1)
+        off_d, lg_d = both[..., :256].view(B, S, 8, L, 4, 2), both[..., 256:].view(B, S, 8, L * 4)
+        assert not off_d.is_contiguous()
+    v = value.to(DEV)
+    args = (shp.to(DEV), start.to(DEV), off_d, lg_d, ref.to(DEV))
+    out = ops.ms_deform_attn_forward_fused(v, *args, algo="window").float().cpu().numpy()
+    direct = ops.ms_deform_attn_forward_fused(v, *args, algo="direct").float().cpu().numpy()
     loc = torch_ref.sampling_locations_from_reference(ref, off.float(), shp, 4)
     w = logits.float().softmax(-1).view(B, S, 8, L, 4)
     expect = torch_ref.msda_core(value.float(), shp, loc, w).numpy()
     _check(out, expect, direct)
-    auto = ops.ms_deform_attn_forward_fused(*dev).float().cpu().numpy()
+    out_h = ops.ms_deform_attn_forward_fused(_head_major(v), *args, value_layout="bhsd", algo="window").float().cpu().numpy()
+    assert np.array_equal(out_h, out)
+    auto = ops.ms_deform_attn_forward_fused(v, *args).float().cpu().numpy()
     assert np.array_equal(auto, direct) or np.array_equal(auto, out)
 
 
-def test_tiled_unsupported_shapes(ops):
+def test_window_unsupported_shapes(ops):
     from relation_detr_amd import _lib
     # five levels
     v, shp, start, loc, attn, S, L = _encoder_inputs([(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], 1, 2.0, 1)
     with pytest.raises(_lib.RdetrError, match="not supported"):
-        ops.ms_deform_attn_forward_strategy("tiled", v.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV))
+        ops.ms_deform_attn_forward(v.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV), algo="window")
     # Nq != S
     v, shp, start, loc, attn, S, L = _encoder_inputs([(64, 96), (32, 48), (16, 24), (8, 12)], 1, 2.0, 2)
     with pytest.raises(_lib.RdetrError, match="not supported"):
-        ops.ms_deform_attn_forward_strategy("tiled", v.to(DEV), shp.to(DEV), start.to(DEV), loc[:, :900].contiguous().to(DEV),
-                                            attn[:, :900].contiguous().to(DEV))
-    # ... while the plain operator serves both through the direct kernel
+        ops.ms_deform_attn_forward(v.to(DEV), shp.to(DEV), start.to(DEV), loc[:, :900].contiguous().to(DEV),
+                                   attn[:, :900].contiguous().to(DEV), algo="window")
+    # ... while the plain operator serves both through the direct kernel, in either layout
     out = ops.ms_deform_attn_forward(v.to(DEV), shp.to(DEV), start.to(DEV), loc[:, :900].contiguous().to(DEV),
                                      attn[:, :900].contiguous().to(DEV), 64)
-    assert out.shape == (1, 900, 256)
+    out_h = ops.ms_deform_attn_forward(_head_major(v.to(DEV)), shp.to(DEV), start.to(DEV), loc[:, :900].contiguous().to(DEV),
+                                       attn[:, :900].contiguous().to(DEV), 64, value_layout="bhsd")
+    assert out.shape == (1, 900, 256) and torch.equal(out, out_h)
+    with pytest.raises(ValueError):
+        ops.ms_deform_attn_forward(v.to(DEV), shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV), algo="fastest")
 
 
-def test_tiled_full_size_properties(ops):
+def test_window_full_size_properties(ops):
     """BASELINE.json configs[1] size (B = 4, S = Nq = 22,323): a constant value map returns the constant wherever all
     samples fall inside the levels (weights sum to one), and two launches on the same inputs are bit-identical (no
     atomics, fixed summation order)."""
@@ -139,11 +180,13 @@ def test_tiled_full_size_properties(ops):
     loc = torch.minimum(torch.maximum(loc, 1.0 / wh), 1.0 - 1.0 / wh).contiguous()
     dev = (shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV))
     const = (torch.arange(256, dtype=torch.float32).view(1, 1, 8, 32) / 64).expand(4, S, 8, 32).contiguous().to(torch.bfloat16)
-    oc = ops.ms_deform_attn_forward_strategy("tiled", const.to(DEV), *dev).float().cpu()
+    oc = ops.ms_deform_attn_forward(const.to(DEV), *dev, algo="window").float().cpu()
     assert (oc - const[:, :1].reshape(4, 1, 256).float()).abs().max().item() <= 2.0 ** -7 * 4
     v = value.to(DEV)
-    o1 = ops.ms_deform_attn_forward_strategy("tiled", v, *dev)
-    o2 = ops.ms_deform_attn_forward_strategy("tiled", v, *dev)
+    o1 = ops.ms_deform_attn_forward(v, *dev, algo="window")
+    o2 = ops.ms_deform_attn_forward(v, *dev, algo="window")
     assert torch.equal(o1, o2)
-    d = ops.ms_deform_attn_forward_strategy("direct", v, *dev).float()
+    d = ops.ms_deform_attn_forward(v, *dev, algo="direct").float()
     assert ((o1.float() - d).abs() <= 2.0 ** -7 * d.abs() + 1e-3).all()
+    oh = ops.ms_deform_attn_forward(_head_major(v), *dev, value_layout="bhsd", algo="window")
+    assert torch.equal(oh, o1)

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     // Issued through inline assembly ON PURPOSE: hipcc tracks the builtin as an LDS write and drains it (s_waitcnt
     // vmcnt(0)) before the pass's first LDS read, which would serialise fill and gather; untracked, it stays in flight
     // behind the MFMA loop and is retired by wn_dma_wait() before the barrier that hands the buffer over.
-    auto fill = [&](int l, int t) {
+    auto fill = [&](int l, int t, int first, int stride) {
         const int *dsc = desc_tab + (t & (kWnRing - 1)) * 16 + l * 4;
         const int wx0 = __builtin_amdgcn_readfirstlane(dsc[0]);
         const int wy0 = __builtin_amdgcn_readfirstlane(dsc[1]);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         const unsigned v0 = (c0 >= 0 && c0 < W) ? (unsigned)c0 * kGPixB + chunk : 0x80000000u;
         const unsigned v1 = (c1 >= 0 && c1 < W) ? (unsigned)c1 * kGPixB + chunk : 0x80000000u;
         const int n = 2 * rh;
-        for (int i = wave; i < n; i += kWnWaves) {                           // uniform
+        for (int i = first; i < n; i += stride) {                            // uniform
             const int r = i >> 1, j = i & 1;
             const int y = wy0 + r;
             const bool rowok = y >= 0 && y < H;
@@ -428,54 +428,66 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wn_bf16x8, af), __builtin_bit_cast(wn_bf16x8, b1), d1, 0, 0, 0);
     };
 
-    // one level of the wave's 16 queries: set-up (lane = query x point) -> staging -> patch -> [next fill] -> MFMA loop
-    auto pass = [&](int l, int t, const WinSamples &sm, auto &&before_loop) {
+    // ---- one level of the wave's 16 queries, in two halves separated by a workgroup barrier ----------------------------
+    // setup (lane = query x point): geometry -> flagged samples' rows -> staging (offsets O, weights W, patch).
+    // Pixel geometry of this lane's sample in level l: msda_fwd.hip's arithmetic (ms_deform_im2col_cuda.cuh:22-73)
+    struct Geo { int x0, y0; bool inside, in_win; float lx, ly; };
+    auto geometry = [&](int l, int t, const WinSamples &sm) {
         const int *dsc = desc_tab + (t & (kWnRing - 1)) * 16 + l * 4;
         const int wx0 = __builtin_amdgcn_readfirstlane(dsc[0]);
         const int wy0 = __builtin_amdgcn_readfirstlane(dsc[1]);
         const int rh = __builtin_amdgcn_readfirstlane(dsc[2]);
         const int W = LW[l], H = LH[l];
-        const unsigned buf = l < 2 ? (unsigned)kWnBufAOff : (unsigned)kWnBufBOff;
-        // msda_fwd.hip's arithmetic (ms_deform_im2col_cuda.cuh:22-73): pixel coordinates, top-left corner, four weights
+        Geo gm;
         const float x = sm.xy[l].x * (float)W - 0.5f;
         const float y = sm.xy[l].y * (float)H - 0.5f;
-        const bool inside = sm.q >= 0 && (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);      // false for NaN
+        gm.inside = sm.q >= 0 && (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);      // false for NaN
         const float xf = floorf(x), yf = floorf(y);
-        const int x0 = inside ? (int)xf : 0, y0 = inside ? (int)yf : 0;       // in [-1, size - 1]
-        const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
-        const float a = sm.a[l];
+        gm.x0 = gm.inside ? (int)xf : 0;                                       // in [-1, size - 1]
+        gm.y0 = gm.inside ? (int)yf : 0;
+        gm.lx = x - xf;
+        gm.ly = y - yf;
+        const int cx = gm.x0 - wx0, cy = gm.y0 - wy0;
+        gm.in_win = (unsigned)cx < (unsigned)(kWnWinW - 1) && (unsigned)cy < (unsigned)(rh - 1);
+        return gm;
+    };
+    // flagged samples `first_rank .. first_rank + 3` (rank = position among the wave's flagged lanes): publish their pixel
+    // coordinates, fetch their rows (lane = sample g, corner tq, 16-byte chunk tp; corners outside the level are out of
+    // range -> zeros, no request), write them where a window would have them: top / bottom corners one pitch apart
+    auto patch_rows = [&](int l, const Geo &gm, bool flagged, int frank, int first_rank, int have) {
+        const int W = LW[l], H = LH[l];
+        if (flagged && frank >= first_rank && frank < first_rank + 4) {
+            fgo[(frank - first_rank) * 2] = gm.x0;
+            fgo[(frank - first_rank) * 2 + 1] = gm.y0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int xx = fgo[g * 2] + (tq & 1), yy = fgo[g * 2 + 1] + (tq >> 1);
+        const bool ok = g < have && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+        const unsigned go = ok ? (unsigned)(LS[l] + yy * W + xx) * kGPixB + (unsigned)tp * 16u : 0x80000000u;
+        const u32x4 pre = __builtin_amdgcn_raw_buffer_load_b128(rsrc, go, 0, 0);
+        *reinterpret_cast<u32x4 *>(wreg + kWnPatchTop + g * 128 + (tq & 1) * 64 + (tq >> 1) * (int)kWnPitchB + tp * 16) = pre;
+    };
+    auto setup = [&](int l, int t, const WinSamples &sm) {
+        const int *dsc = desc_tab + (t & (kWnRing - 1)) * 16 + l * 4;
+        const int wx0 = __builtin_amdgcn_readfirstlane(dsc[0]);
+        const int wy0 = __builtin_amdgcn_readfirstlane(dsc[1]);
+        const unsigned buf = l < 2 ? (unsigned)kWnBufAOff : (unsigned)kWnBufBOff;
+        const Geo gm = geometry(l, t, sm);
+        const float hx = 1.f - gm.lx, hy = 1.f - gm.ly, a = sm.a[l];
         // corners outside the level read zeros (window border / range-checked patch loads): no per-corner masks
-        const float w00 = inside ? hy * hx * a : 0.f, w01 = inside ? hy * lx * a : 0.f;
-        const float w10 = inside ? ly * hx * a : 0.f, w11 = inside ? ly * lx * a : 0.f;
-        const int cx = x0 - wx0, cy = y0 - wy0;
-        const bool in_win = (unsigned)cx < (unsigned)(kWnWinW - 1) && (unsigned)cy < (unsigned)(rh - 1);
-        const bool flagged = inside && !in_win;
+        const float w00 = gm.inside ? hy * hx * a : 0.f, w01 = gm.inside ? hy * gm.lx * a : 0.f;
+        const float w10 = gm.inside ? gm.ly * hx * a : 0.f, w11 = gm.inside ? gm.ly * gm.lx * a : 0.f;
+        const bool flagged = gm.inside && !gm.in_win;
         const unsigned long long fmask0 = __ballot(flagged);
         const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask0, 0));
-        unsigned o = lds0 + (unsigned)kWnZeroOff + par32;                            // not inside, or flagged beyond the first four
-        if (inside && in_win) o = lds0 + buf + (unsigned)cy * kWnPitchB + (unsigned)cx * kWnPixB + par32;
+        unsigned o = lds0 + (unsigned)kWnZeroOff + par32;                     // not inside, or flagged beyond the first four
+        if (gm.inside && gm.in_win)
+            o = lds0 + buf + (unsigned)(gm.y0 - wy0) * kWnPitchB + (unsigned)(gm.x0 - wx0) * kWnPixB + par32;
         if (flagged && frank < 4) o = lds0 + wave_off + (unsigned)kWnPatchTop + (unsigned)frank * 128u + par32;
-        // flagged samples: publish the pixel coordinates of (up to) four, fetch their rows (lane = sample g, corner tq,
-        // 16-byte chunk tp; corners outside the level are out of range -> zeros, no request)
-        u32x4 pre = {0u, 0u, 0u, 0u};
-        auto issue_patch_loads = [&](int first_rank, int have) {
-            if (flagged && frank >= first_rank && frank < first_rank + 4) {
-                fgo[(frank - first_rank) * 2] = x0;
-                fgo[(frank - first_rank) * 2 + 1] = y0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int xx = fgo[g * 2] + (tq & 1), yy = fgo[g * 2 + 1] + (tq >> 1);
-            const bool ok = g < have && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
-            const unsigned go = ok ? (unsigned)(LS[l] + yy * W + xx) * kGPixB + (unsigned)tp * 16u : 0x80000000u;
-            pre = __builtin_amdgcn_raw_buffer_load_b128(rsrc, go, 0, 0);
-        };
-        auto write_patch = [&]() {            // row (sample g, corner tq) where a window would have it: top / bottom pitch apart
-            *reinterpret_cast<u32x4 *>(wreg + kWnPatchTop + g * 128 + (tq & 1) * 64 + (tq >> 1) * (int)kWnPitchB + tp * 16) = pre;
-        };
         const int nflag = __builtin_popcountll(fmask0);                       // uniform
-        if (nflag) issue_patch_loads(0, nflag);
+        if (nflag) patch_rows(l, gm, flagged, frank, 0, nflag);
         unsigned h01, h23, l01, l23;
         wn_split2(w00, w01, h01, l01);
         wn_split2(w10, w11, h23, l23);
@@ -485,13 +497,12 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
             sw[0] = u32x2{h01, h23};
             sw[4] = u32x2{l01, l23};
         }
-        if (nflag) write_patch();              // waits for the rows; the other waves of the SIMD run meanwhile
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // staging is private to the wave: wave-level ordering suffices
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        before_loop();                         // the next window's DMA (and in pass 3 the next tile's locations) start here
+        return nflag;
+    };
 
-        // per (octet, quad half): one 16-byte read brings the top-left offsets of all four points, then two steps
+    // gather: the MFMA loop over the staged samples -- per (octet, quad half) one 16-byte read brings the top-left offsets
+    // of all four points, then two steps
+    auto gather = [&](int l, int t, const WinSamples &sm, int nflag) {
         if (!(dbg & 32))
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
@@ -503,18 +514,19 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
                 mfma_step(wa + 16, so.z + cd, so.w + cd, acc[op][0], acc[op][1]);
             }
         }
-
         // more than four flagged samples (rare): four at a time through the patch, one MFMA step per sample with every
         // other row of the operand pointing at the zero sample
         if (nflag > 4) {
-            unsigned long long fmask = fmask0;
+            const Geo gm = geometry(l, t, sm);
+            const bool flagged = gm.inside && !gm.in_win;
+            unsigned long long fmask = __ballot(flagged);
+            const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0));
             for (int k = 0; k < 4; ++k) fmask &= fmask - 1;          // the first four went through the loop above
             int done = 4;
             while (fmask != 0ull) {                                  // uniform
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                issue_patch_loads(done, nflag - done);
-                write_patch();
+                patch_rows(l, gm, flagged, frank, done, nflag - done);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -536,8 +548,6 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
                 done += 4;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads before the next pass's staging writes
-        __builtin_amdgcn_wave_barrier();
     };
 
     // out[query][channel] = D[hi row] + D[lo row]; transposed through the wave's region so that a lane stores 16 bytes
@@ -580,14 +590,30 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     };
     if (tid < kWnRing * 16) tables_for(t0 + (tid >> 4), tid & 15);
     __syncthreads();
-    WinSamples cur;                        // ONE register set: the next tile's locations are loaded in pass 3, after the
-    load_samples(t0, cur);                 // last set-up of the current tile has consumed them
+    WinSamples cur;                        // the current tile's samples; the next tile's are loaded in pass 3 (below)
+    load_samples(t0, cur);
 #pragma unroll
     for (int l = 0; l < kWnLevels; ++l) asm volatile("" ::"v"(cur.xy[l].x), "v"(cur.xy[l].y), "v"(cur.a[l]));   // retire the loads
-    fill(0, t0);
+    fill(0, t0, wave, kWnWaves);
     wn_dma_wait();
     __syncthreads();
 
+    // Half-phases.  A pass (one sampled level) is setup | barrier | gather | barrier, and the two halves of the workgroup
+    // run it ONE HALF-PHASE APART: while waves 0..7 gather (LDS reads + MFMA) waves 8..15 set up (VALU) and vice versa --
+    // in lockstep the two pipes took turns (measured: set-up 27 us + gather 46 us of a 142-us kernel, nothing overlapping).
+    // Every wave executes the same sequence; the late half just starts one barrier later and ends one barrier earlier.
+    //   window of pass P: read in half-phases 2P + 1 (early half) and 2P + 2 (late half); its buffer is re-filled for pass
+    //   P + 2 from half-phase 2P + 3 on: the LATE half issues that fill at the start of its set-up of pass P + 1 and
+    //   retires it before the barrier that ends its gather of pass P + 1 (two half-phases to land).  The early half never
+    //   has DMA in flight, so its location loads cross barriers freely.
+    const bool late = wave >= kWnWaves / 2;
+    auto hp_barrier = [&](bool retire_dma) {
+        if (retire_dma) wn_dma_wait();
+        __syncthreads();
+    };
+    if (late) hp_barrier(false);
+
+    // levels in pass order, and the window that is filled while pass p is worked on (level, tile offset)
     for (int t = t0; t < t1; ++t) {
         const bool has_next = t + 1 < t1;
         const bool busy = __ballot(cur.q >= 0) != 0ull;  // any query in this wave?
@@ -595,45 +621,50 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         for (int op = 0; op < 2; ++op)
 #pragma unroll
             for (int X = 0; X < 2; ++X) acc[op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // pass 0: level 0 from A   | level 2 -> B in flight
-        if (busy && !(dbg & 4)) pass(0, t, cur, [&] { if (!(dbg & 2)) fill(2, t); });
-        else if (!(dbg & 2)) fill(2, t);
-        wn_dma_wait();
-        __syncthreads();
-
-        // pass 1: level 2 from B   | level 1 -> A in flight
-        if (busy && !(dbg & 4)) pass(2, t, cur, [&] { if (!(dbg & 2)) fill(1, t); });
-        else if (!(dbg & 2)) fill(1, t);
-        wn_dma_wait();
-        __syncthreads();
-
-        // pass 2: level 1 from A   | level 3 -> B in flight
-        if (busy && !(dbg & 4)) pass(1, t, cur, [&] { if (!(dbg & 2)) fill(3, t); });
-        else if (!(dbg & 2)) fill(3, t);
-        wn_dma_wait();
-        __syncthreads();
-
-        if (t > t0 && ((t - t0) & 7) == 0 && tid < 128) tables_for(t + 8 + (tid >> 4), tid & 15);      // entries of tiles t - 8 .. t - 1 are dead
-        // pass 3: level 3 from B   | next tile's level 0 -> A in flight; its locations are fetched behind the MFMA loop
         const int sq = cur.q;
-        if (busy && !(dbg & 4)) {
-            pass(3, t, cur, [&] {
-                if (has_next && !(dbg & 2)) fill(0, t + 1);
-                if (has_next && !(dbg & 16)) load_samples(t + 1, cur);
-            });
-        } else {
-            if (has_next && !(dbg & 2)) fill(0, t + 1);
-            if (has_next && !(dbg & 16)) load_samples(t + 1, cur);
-        }
-        if (busy && !(dbg & 8)) store_tile(sq);
-        // make the compiler retire the location loads HERE (it waits lazily, at the first use -- which would be inside the
-        // next pass, behind that pass's untracked DMA, and would drain it)
+        f32x2 nxy3 = {0.f, 0.f};           // next tile: level 3 of its samples (levels 0..2 are loaded into `cur` in place)
+        float na3 = 0.f;
+        int nq = -1;
+
+        auto one_pass = [&](int p, int l, int fl, int ft, bool do_fill) {
+            // early half: [setup] barrier [gather] barrier;   late half: [issue fill, setup] barrier [gather | retire fill] barrier
+            int nflag = 0;
+            if (late && do_fill && !(dbg & 2)) fill(fl, ft, wave - kWnWaves / 2, kWnWaves / 2);
+            if (busy && !(dbg & 4)) nflag = setup(l, t, cur);
+            if (p == 3 && has_next && !(dbg & 16)) {
+                // the last set-up of the tile has consumed levels 0..2 of `cur`: fetch the next tile's samples behind the gather
+                WinSamples nx;
+                load_samples(t + 1, nx);
 #pragma unroll
-        for (int l = 0; l < kWnLevels; ++l) asm volatile("" ::"v"(cur.xy[l].x), "v"(cur.xy[l].y), "v"(cur.a[l]));
-        wn_dma_wait();
-        __syncthreads();
+                for (int k = 0; k < 3; ++k) { cur.xy[k] = nx.xy[k]; cur.a[k] = nx.a[k]; }
+                nxy3 = nx.xy[3]; na3 = nx.a[3]; nq = nx.q;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // staging is private to the wave: wave-level ordering suffices
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            hp_barrier(false);
+            if (busy && !(dbg & 4)) gather(l, t, cur, nflag);
+            if (p == 3) {
+                if (busy && !(dbg & 8)) store_tile(sq);
+                if (has_next && !(dbg & 16)) {
+                    cur.xy[3] = nxy3; cur.a[3] = na3; cur.q = nq;
+                    // make the compiler retire the location loads HERE (it waits lazily, at the first use -- which would
+                    // be inside the next set-up, behind untracked DMA, and would drain it)
+#pragma unroll
+                    for (int k = 0; k < kWnLevels; ++k) asm volatile("" ::"v"(cur.xy[k].x), "v"(cur.xy[k].y), "v"(cur.a[k]));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads before the next pass's staging writes
+            __builtin_amdgcn_wave_barrier();
+            hp_barrier(late);
+        };
+        one_pass(0, 0, 2, t, true);                  // level 0 from A | level 2 -> B
+        one_pass(1, 2, 1, t, true);                  // level 2 from B | level 1 -> A
+        if (t > t0 && ((t - t0) & 7) == 0 && tid < 128) tables_for(t + 8 + (tid >> 4), tid & 15);      // entries of tiles t - 8 .. t - 1 are dead
+        one_pass(2, 1, 3, t, true);                  // level 1 from A | level 3 -> B
+        one_pass(3, 3, 0, t + 1, has_next);          // level 3 from B | next tile's level 0 -> A
     }
+    if (!late) hp_barrier(false);
 }
 
 #ifdef RDETR_DEV

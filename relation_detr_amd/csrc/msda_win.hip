@@ -7,7 +7,7 @@
 // 3.5x that rate, and a spatial tile of queries re-uses every row it stages about six times.
 //
 //   tile      a 16 x 12 pixel region of level 0 plus the pixels of the coarser levels whose centres fall into it
-//             (<= 192 + 64 queries); waves 0..11 own the region's rows, waves 12..15 its coarser pixels.
+//             (<= 192 + 64 queries); slots 0..11 own the region's rows, slots 12..15 its coarser pixels.
 //   windows   per tile and sampled level a 32-pixel-wide window of the (image, head) value plane around the tile's
 //             footprint in that level (28 rows for levels 0 / 1, 19 for levels 2 / 3), IN PADDED COORDINATES: the window
 //             may start at pixel -1 and end at pixel W, and whatever lies outside the level arrives as zeros -- the
@@ -33,11 +33,18 @@
 //             locations; more than four such samples per wave and level take extra steps (a decoder-like scatter
 //             merely runs slowly).  The result never depends on the windows.
 //
-//   workgroup = 1024 threads = 16 waves, persistent over a contiguous range of the tiles of ONE (image, head).
-//   passes    = one per sampled level, order L0 (A), L2 (B), L1 (A), L3 (B): the two window buffers alternate, the
-//               fill of the next pass is issued before the MFMA loop of the current one; one barrier per pass.
+//   workgroup = 512 threads = 8 waves with TWO 16-query slots each (256 registers per lane: the set-up of one pass and the
+//               gather of another are live together), persistent over a contiguous range of the tiles of ONE (image, head).
+//   passes    = one per sampled level, order L0 (A), L2 (B), L1 (A), L3 (B): the two window buffers alternate, the fill of
+//               the next pass is issued at the top of the current one; one barrier per pass.  A pass GATHERS its level
+//               (LDS reads + MFMA) and SETS UP the next pass (VALU; results kept in registers, staged to LDS at the end):
+//               the two are independent, and the two waves of a SIMD run them in opposite order, so that the LDS and
+//               the vector ALU work at the same time (in lockstep they took turns: set-up 27 us + gather 46 us of a
+//               142-us kernel, nothing overlapping).
 // Per corner the arithmetic is msda_fwd.hip's (same weights); the summation order differs and each weight carries a
 // 2^-17 relative representation error (the bf16 output rounds at 2^-9).
+#include <type_traits>
+
 #include "common.h"
 
 namespace rdetr {
@@ -46,11 +53,13 @@ typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
 typedef short wn_s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWnThreads = 1024;
-constexpr int kWnWaves = kWnThreads / kWave;
-constexpr int kWnRegW = 16, kWnRegH = 12;                     // level-0 pixels of a spatial tile: one row per wave 0..11
-constexpr int kWnCoarseWave0 = kWnRegH;                       // waves 12..15: the region's coarser-level queries
-constexpr int kWnCoarseSlots = (kWnWaves - kWnCoarseWave0) * 16;
+constexpr int kWnThreads = 512;
+constexpr int kWnWaves = kWnThreads / kWave;                  // 8
+constexpr int kWnSlotsPerWave = 2;
+constexpr int kWnSlots = kWnWaves * kWnSlotsPerWave;          // 16 groups of 16 queries per tile
+constexpr int kWnRegW = 16, kWnRegH = 12;                     // level-0 pixels of a spatial tile: one row per slot 0..11
+constexpr int kWnCoarseSlot0 = kWnRegH;                       // slots 12..15: the region's coarser-level queries
+constexpr int kWnCoarseSlots = (kWnSlots - kWnCoarseSlot0) * 16;
 constexpr int kWnHeads = 8, kWnHeadDim = 32, kWnPoints = 4, kWnLevels = 4;
 constexpr unsigned kWnPixB = 64;                              // LDS bytes per pixel (one bf16 head row)
 constexpr int kWnWinW = 32;                                   // window width in pixels = two DMA instructions per row
@@ -60,7 +69,7 @@ constexpr int kWnMargin = 8;                                  // rows / columns 
 constexpr int kWnRing = 16;                                   // tiles whose geometry / window tables are kept (ring)
 
 // ---- LDS map ------------------------------------------------------------------------------------------------------
-constexpr int kWnFgoOff = 512;                                // 16 waves x 64 B: pixel coordinates of the flagged samples in flight
+constexpr int kWnFgoOff = 512;                                // 16 slots x 64 B: pixel coordinates of the flagged samples in flight
 constexpr int kWnGeoOff = 1536;                               // int geo[kWnRing][20]
 constexpr int kWnDescOff = kWnGeoOff + kWnRing * 80;          // int desc[kWnRing][4 levels][4]
 constexpr int kWnZeroOff = 4096;                              // 1 KiB of zeros: idle A-operand lanes; its first 128 B = the
@@ -69,18 +78,19 @@ constexpr int kWnZeroBotOff = kWnZeroOff + (int)kWnPitchB;    // 128 B of zeros 
 constexpr int kWnZeroKOff = kWnZeroOff + 128 + 32;            // what idle A lanes read; == 32 (mod 64) keeps it off the live lanes' banks
 constexpr int kWnMiscBytes = kWnZeroBotOff + 128;             // 6400
 static_assert(kWnDescOff + kWnRing * 64 <= kWnZeroOff, "tables overlap the zero block");
-// per-wave region (one window pitch + 512 B): the patch mimics a piece of window -- top corners of flagged sample k at
-// k * 128, bottom corners one pitch further -- and the staging sits between the two
-constexpr int kWnWaveOff = kWnMiscBytes;
-constexpr int kWnWaveBytes = (int)kWnPitchB + 512;            // 2688
-constexpr int kWnPatchTop = 0;                                // [0, 512)
-constexpr int kWnStageW = 512;                                // [512, 1536)  W[query][part][point][corner] bf16
-constexpr int kWnStageO = 1536;                               // [1536, 1792) O[query][point] u32 LDS offsets of the top-left corners
-constexpr int kWnBufAOff = kWnWaveOff + kWnWaves * kWnWaveBytes;
+// per-slot region: two patch buffers (the rows of up to four flagged samples each, 256 B per sample = four corners of 64 B;
+// one is read by the gather of pass p while the DMA for pass p + 1 lands in the other), then the staging
+constexpr int kWnSlotOff = kWnMiscBytes;
+constexpr int kWnPatch = 0;                                   // [0, 1024) buffer 0, [1024, 2048) buffer 1
+constexpr int kWnStageW = 2048;                               // [2048, 3072) W[query][part][point][corner] bf16
+constexpr int kWnStageO = 3072;                               // [3072, 3328) O[query][point] u32: LDS offset of the top-left corner;
+                                                              // bit 31 = a patch sample (corners 64 B apart instead of window-shaped)
+constexpr int kWnSlotBytes = 3328;
+constexpr int kWnBufAOff = kWnSlotOff + kWnSlots * kWnSlotBytes;
 constexpr int kWnBufBOff = kWnBufAOff + kWnRowsA * (int)kWnPitchB;
 constexpr int kWnLdsBytes = kWnBufBOff + kWnRowsB * (int)kWnPitchB;
 static_assert(kWnLdsBytes <= 160 * 1024, "LDS map exceeds 160 KiB");
-static_assert(kWnWaveBytes % 64 == 0 && kWnBufAOff % 256 == 0, "window buffers must keep the bank phase of the pitch");
+static_assert(kWnSlotBytes % 256 == 0 && kWnBufAOff % 256 == 0, "window buffers must keep the bank phase of the pitch");
 
 struct WinShared {
     int h[kWnLevels], w[kWnLevels], start[kWnLevels];
@@ -93,8 +103,8 @@ static_assert(sizeof(WinShared) <= kWnFgoOff, "tables overlap");
 //   desc[4][4]   per level: window origin x, y in pixel coordinates (>= -1), rows, -
 
 struct WinSamples {                        // lane (query = lane >> 2, point = lane & 3): its sample in each level
-    f32x2 xy[kWnLevels];
-    float a[kWnLevels];
+    f32x2 xy[kWnLevels];                   // FUSED, before finalize(): raw (offset x, offset y)
+    float a[kWnLevels];                    //                           raw attention logit
     int q;                                 // query index of lane >> 2, -1 = none
 };
 
@@ -109,6 +119,11 @@ __device__ __forceinline__ float wn_quad_sum(float v)
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
     return v;
+}
+// value of lane (quad, L) for every lane of the quad (DPP quad_perm broadcast)
+template <int L> __device__ __forceinline__ float wn_quad_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), L * 0x55, 0xf, 0xf, false));
 }
 
 // a / b for a < 2^24, 0 < b < 2^24 without the integer division sequence: the float quotient is within one of the exact
@@ -141,7 +156,7 @@ __device__ __forceinline__ void wn_split2(float a, float b, unsigned &hi, unsign
     lo = __builtin_bit_cast(unsigned, wn_bf16x2{(__bf16)ra, (__bf16)rb});
 }
 
-// retire this wave's LDS-DMA before the barrier that publishes the buffer (the compiler does not know about it)
+// retire this wave's LDS-DMA before the barrier that publishes the buffers (the compiler does not know about it)
 __device__ __forceinline__ void wn_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // HM = false: value [B,S,H,D] (pixel-major, the reference operator's layout); HM = true: value [B,H,S,D] (head-major).
@@ -227,26 +242,24 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(plane), 0, plane_bytes, 0x00020000);
 
-    // set-up role: query qx of the wave, point pp.   gather role: K-group g, corner tq / piece tp of a transposed read;
+    // set-up role: query qx of the slot, point pp.   gather role: K-group g, corner tq / piece tp of a transposed read;
     // as an A-operand lane: row am = lane & 15 = 8 * (quad half ah) + 2 * (K-group ag) + (0 = bf16 high part, 1 = low part)
     const int qx = lane >> 2, pp = lane & 3;
     const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
     const int am = lane & 15, ah = am >> 3, ag = (am >> 1) & 3, apart = am & 1;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;     // 0 in practice
-    const unsigned wave_off = (unsigned)(kWnWaveOff + wave * kWnWaveBytes);
-    unsigned char *wreg = lds + wave_off;
+    // slot s of this wave = group 2 * wave + s of the tile's 16 groups of 16 queries; its LDS region:
+    auto slot_off = [&](int s) { return (unsigned)(kWnSlotOff + (kWnSlotsPerWave * wave + s) * kWnSlotBytes); };     // scalar
     // One MFMA step = octet o', quad half h, point pair j: K-group g carries the two samples (points 2j, 2j + 1) of
     // query 8 o' + 4 h + g; its lane (corner tq, piece tp) reads row `top-left + cd` of each.
     const unsigned cd = (unsigned)(tq & 1) * kWnPixB + (unsigned)(tq >> 1) * kWnPitchB + (unsigned)tp * 8u;
-    const unsigned o_rd = lds0 + wave_off + (unsigned)kWnStageO + (unsigned)g * 16u;                   // + (8 o' + 4 h) * 16
+    const unsigned cdp = (unsigned)tq * kWnPixB + (unsigned)tp * 8u;          // ... of a patch sample
     // A operand: lane (row am, K-group g) is live only in the steps of its own quad half and only if its row's query is the
     // K-group's -- then it reads that query's 2 x 4 weights (16 B); otherwise 16 B of zeros.  + o' * 512 + j * 16
-    const unsigned w_real = lds0 + wave_off + (unsigned)kWnStageW + (unsigned)((4 * ah + g) * 64 + apart * 32);
-    const unsigned w_rd0 = (ag == g && ah == 0) ? w_real : lds0 + (unsigned)kWnZeroKOff;
-    const unsigned w_rd1 = (ag == g && ah == 1) ? w_real : lds0 + (unsigned)kWnZeroKOff;
+    const unsigned w_lane = (unsigned)kWnStageW + (unsigned)((4 * ah + g) * 64 + apart * 32);
+    const bool a_live0 = ag == g && ah == 0, a_live1 = ag == g && ah == 1;
     const unsigned par32 = (unsigned)(qx & 1) * 32u;              // odd queries read the other channel half first: the two
                                                                   // K-groups of a 32-lane half never share a bank group
-    int *fgo = reinterpret_cast<int *>(lds + kWnFgoOff + wave * 64);
 
     // ---- helpers -----------------------------------------------------------------------------------------------
     // Tile geometry (which region, and which pixels of the coarser levels have their centres in it) costs a dozen integer
@@ -269,16 +282,17 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         }
     };
 
-    // query owned by lane >> 2 of this wave in tile t (-1 = none)
-    auto query_of = [&](int t) -> int {
+    // query owned by lane >> 2 of slot s in tile t (-1 = none)
+    auto query_of = [&](int t, int s) -> int {
+        const int grp = kWnSlotsPerWave * wave + s;
         const int *geo = geo_tab + (t & (kWnRing - 1)) * 20;
         const int rx = __builtin_amdgcn_readfirstlane(geo[0]), ry = __builtin_amdgcn_readfirstlane(geo[1]);
         const int chunk = __builtin_amdgcn_readfirstlane(geo[2]);
-        if (wave < kWnCoarseWave0) {
-            const int x = rx * kWnRegW + qx, y = ry * kWnRegH + wave;
+        if (grp < kWnCoarseSlot0) {
+            const int x = rx * kWnRegW + qx, y = ry * kWnRegH + grp;
             return (chunk == 0 && x < LW[0] && y < LH[0]) ? LS[0] + y * LW[0] + x : -1;
         }
-        int j = chunk * kWnCoarseSlots + (wave - kWnCoarseWave0) * 16 + qx;
+        int j = chunk * kWnCoarseSlots + (grp - kWnCoarseSlot0) * 16 + qx;
         int q = -1;
 #pragma unroll
         for (int l = 1; l < kWnLevels; ++l) {
@@ -296,9 +310,10 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         return q;
     };
 
-    // sampling locations / attention weights of this lane's (query, point) in every level
-    auto load_samples = [&](int t, WinSamples &sm) {
-        sm.q = query_of(t);
+    // sampling locations / attention weights of this lane's (query, point) in every level: the LOADS only -- with FUSED the
+    // raw projection outputs, which finalize() turns into locations / weights once they have landed
+    auto load_samples = [&](int t, int s, WinSamples &sm, f32x4 &rf) {   // rf (FUSED): the reference point of level `lane & 3`
+        sm.q = query_of(t, s);
         const size_t row = (size_t)b * Nq + (sm.q >= 0 ? sm.q : 0);
         const size_t hrow = (row * kWnHeads + m) * (size_t)(kWnLevels * kWnPoints);
         if constexpr (FUSED) {
@@ -307,34 +322,19 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
                                     (ld_a ? row * (size_t)ld_a + (size_t)m * (kWnLevels * kWnPoints * 2) : hrow * 2);
             const uint16_t *lg_q = static_cast<const uint16_t *>(src_b) +
                                    (ld_b ? row * (size_t)ld_b + (size_t)m * (kWnLevels * kWnPoints) : hrow);
-            float mx = -__builtin_inff();
 #pragma unroll
             for (int l = 0; l < kWnLevels; ++l) {
                 const int pt = l * kWnPoints + pp;
                 sm.a[l] = bf16_bits_to_f32(lg_q[pt]);
                 const unsigned u = *reinterpret_cast<const unsigned *>(off_q + 2 * pt);
                 sm.xy[l] = f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
-                mx = fmaxf(mx, sm.a[l]);
             }
-            mx = wn_quad_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int l = 0; l < kWnLevels; ++l) {
-                sm.a[l] = expf(sm.a[l] - mx);
-                sum += sm.a[l];
-            }
-            sum = wn_quad_sum(sum);
-#pragma unroll
-            for (int l = 0; l < kWnLevels; ++l) {
-                const float *rp = ref + (row * kWnLevels + l) * (size_t)ref_dim;
-                sm.a[l] = sm.a[l] / sum;
-                if (ref_dim == 2) {
-                    sm.xy[l].x = rp[0] + sm.xy[l].x / (float)LW[l];
-                    sm.xy[l].y = rp[1] + sm.xy[l].y / (float)LH[l];
-                } else {
-                    sm.xy[l].x = rp[0] + sm.xy[l].x * (1.0f / kWnPoints) * rp[2] * 0.5f;
-                    sm.xy[l].y = rp[1] + sm.xy[l].y * (1.0f / kWnPoints) * rp[3] * 0.5f;
-                }
+            const float *rp = ref + (row * kWnLevels + pp) * (size_t)ref_dim;        // lane pp: the reference point of level pp
+            if (ref_dim == 2) {
+                const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
+                rf = f32x4{r2.x, r2.y, 0.f, 0.f};
+            } else {
+                rf = *reinterpret_cast<const f32x4 *>(rp);
             }
         } else {
             // 32-bit element offsets from the image's (uniform) base: B * Nq * 8 * 16 * 2 floats can exceed 2^32, one image cannot
@@ -346,6 +346,38 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
                 sm.xy[l] = *reinterpret_cast<const f32x2 *>(loc_b + 2u * (e + (unsigned)(l * kWnPoints)));
                 sm.a[l] = att_b[e + (unsigned)(l * kWnPoints)];
             }
+        }
+    };
+    // FUSED: softmax over the L * P logits of a (query, head) and  loc = ref + off / (W, H)  |  ref_xy + off / P * ref_wh * 0.5
+    // (ms_deform_attn.py:326-349), in the reference's operation order
+    auto finalize = [&](WinSamples &sm, const f32x4 &rf) {
+        if constexpr (FUSED) {
+            float mx = fmaxf(fmaxf(sm.a[0], sm.a[1]), fmaxf(sm.a[2], sm.a[3]));
+            mx = wn_quad_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int l = 0; l < kWnLevels; ++l) {
+                sm.a[l] = expf(sm.a[l] - mx);
+                sum += sm.a[l];
+            }
+            sum = wn_quad_sum(sum);
+            auto level = [&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                const float rx = wn_quad_bcast<l>(rf.x), ry = wn_quad_bcast<l>(rf.y);
+                sm.a[l] = sm.a[l] / sum;
+                if (ref_dim == 2) {
+                    sm.xy[l].x = rx + sm.xy[l].x / (float)LW[l];
+                    sm.xy[l].y = ry + sm.xy[l].y / (float)LH[l];
+                } else {
+                    const float rw = wn_quad_bcast<l>(rf.z), rh = wn_quad_bcast<l>(rf.w);
+                    sm.xy[l].x = rx + sm.xy[l].x * (1.0f / kWnPoints) * rw * 0.5f;
+                    sm.xy[l].y = ry + sm.xy[l].y * (1.0f / kWnPoints) * rh * 0.5f;
+                }
+            };
+            level(std::integral_constant<int, 0>{});
+            level(std::integral_constant<int, 1>{});
+            level(std::integral_constant<int, 2>{});
+            level(std::integral_constant<int, 3>{});
         }
     };
 
@@ -384,8 +416,8 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     // per-lane offset is one of two constants of the fill (column * pixel pitch + 16-byte chunk, or "out of range").
     // Issued through inline assembly ON PURPOSE: hipcc tracks the builtin as an LDS write and drains it (s_waitcnt
     // vmcnt(0)) before the pass's first LDS read, which would serialise fill and gather; untracked, it stays in flight
-    // behind the MFMA loop and is retired by wn_dma_wait() before the barrier that hands the buffer over.
-    auto fill = [&](int l, int t, int first, int stride) {
+    // behind the pass and is retired by wn_dma_wait() before the barrier that hands the buffer over.
+    auto fill = [&](int l, int t) {
         const int *dsc = desc_tab + (t & (kWnRing - 1)) * 16 + l * 4;
         const int wx0 = __builtin_amdgcn_readfirstlane(dsc[0]);
         const int wy0 = __builtin_amdgcn_readfirstlane(dsc[1]);
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         const unsigned v0 = (c0 >= 0 && c0 < W) ? (unsigned)c0 * kGPixB + chunk : 0x80000000u;
         const unsigned v1 = (c1 >= 0 && c1 < W) ? (unsigned)c1 * kGPixB + chunk : 0x80000000u;
         const int n = 2 * rh;
-        for (int i = first; i < n; i += stride) {                            // uniform
+        for (int i = wave; i < n; i += kWnWaves) {                           // uniform
             const int r = i >> 1, j = i & 1;
             const int y = wy0 + r;
             const bool rowok = y >= 0 && y < H;
@@ -411,7 +443,7 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         }
     };
 
-    f32x4 acc[2][2];                       // [octet o'][X]: D rows 4g + r of a lane = query 8 o' + 2g + (r >> 1), part r & 1,
+    f32x4 acc[kWnSlotsPerWave][2][2];      // [slot][octet o'][X]: D rows 4g + r of a lane = query 8 o' + 2g + (r >> 1), part r & 1,
                                            // channel (lane & 15) + 16 ((r >> 1) ^ X)
 
     auto lds_b128 = [](unsigned a) { return *(__attribute__((address_space(3))) const u32x4 *)a; };
@@ -428,81 +460,91 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wn_bf16x8, af), __builtin_bit_cast(wn_bf16x8, b1), d1, 0, 0, 0);
     };
 
-    // ---- one level of the wave's 16 queries, in two halves separated by a workgroup barrier ----------------------------
-    // setup (lane = query x point): geometry -> flagged samples' rows -> staging (offsets O, weights W, patch).
-    // Pixel geometry of this lane's sample in level l: msda_fwd.hip's arithmetic (ms_deform_im2col_cuda.cuh:22-73)
-    struct Geo { int x0, y0; bool inside, in_win; float lx, ly; };
-    auto geometry = [&](int l, int t, const WinSamples &sm) {
+    // ---- one level of a slot's 16 queries: set-up into REGISTERS, staged to LDS at the end of the previous pass ---------
+    struct Staged {                        // what a lane carries from its set-up to the end of the pass
+        unsigned o, h01, h23, l01, l23;    // O entry (below); bf16 high / low parts of the four corner weights
+    };
+    // O entry of a sample, by its two top bits:  0x = LDS offset of its top-left corner in a window (or of the zero sample);
+    // 10 = ... in a patch buffer (corners 64 B apart);  11 = flagged beyond the slot's first four ("overflow"): the low 30 bits
+    // are its top-left pixel ((y0 + 1) << 15 | (x0 + 1)), the main loop reads the zero sample and extra steps serve it
+    // flagged samples `first_rank .. first_rank + 3`: publish their pixel coordinates; -> this lane's (sample g, corner tq,
+    // 16-byte chunk tp) byte offset in the value plane (corners outside the level: out of range -> zeros, no request)
+    auto patch_offset = [&](int l, int s, unsigned pk, int frank, int first_rank, int have) -> unsigned {
+        const int W = LW[l], H = LH[l];
+        int *fgo = reinterpret_cast<int *>(lds + kWnFgoOff + (kWnSlotsPerWave * wave + s) * 64);
+        if (frank >= first_rank && frank < first_rank + 4) fgo[frank - first_rank] = (int)pk;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int pxy = fgo[g];
+        const int xx = (pxy & 0x7fff) - 1 + (tq & 1), yy = (pxy >> 15) - 1 + (tq >> 1);
+        const bool ok = g < have && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+        return ok ? (unsigned)(LS[l] + yy * W + xx) * kGPixB + (unsigned)tp * 16u : 0x80000000u;
+    };
+    // set-up of this lane's sample (query qx, point pp) of slot s in level l of tile t: msda_fwd.hip's arithmetic
+    // (ms_deform_im2col_cuda.cuh:22-73); nothing is written to LDS except the flagged samples' coordinates
+    auto setup = [&](int l, int t, int s, f32x2 sxy, float a, bool qok, int pbuf) -> Staged {
         const int *dsc = desc_tab + (t & (kWnRing - 1)) * 16 + l * 4;
         const int wx0 = __builtin_amdgcn_readfirstlane(dsc[0]);
         const int wy0 = __builtin_amdgcn_readfirstlane(dsc[1]);
         const int rh = __builtin_amdgcn_readfirstlane(dsc[2]);
         const int W = LW[l], H = LH[l];
-        Geo gm;
-        const float x = sm.xy[l].x * (float)W - 0.5f;
-        const float y = sm.xy[l].y * (float)H - 0.5f;
-        gm.inside = sm.q >= 0 && (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);      // false for NaN
-        const float xf = floorf(x), yf = floorf(y);
-        gm.x0 = gm.inside ? (int)xf : 0;                                       // in [-1, size - 1]
-        gm.y0 = gm.inside ? (int)yf : 0;
-        gm.lx = x - xf;
-        gm.ly = y - yf;
-        const int cx = gm.x0 - wx0, cy = gm.y0 - wy0;
-        gm.in_win = (unsigned)cx < (unsigned)(kWnWinW - 1) && (unsigned)cy < (unsigned)(rh - 1);
-        return gm;
-    };
-    // flagged samples `first_rank .. first_rank + 3` (rank = position among the wave's flagged lanes): publish their pixel
-    // coordinates, fetch their rows (lane = sample g, corner tq, 16-byte chunk tp; corners outside the level are out of
-    // range -> zeros, no request), write them where a window would have them: top / bottom corners one pitch apart
-    auto patch_rows = [&](int l, const Geo &gm, bool flagged, int frank, int first_rank, int have) {
-        const int W = LW[l], H = LH[l];
-        if (flagged && frank >= first_rank && frank < first_rank + 4) {
-            fgo[(frank - first_rank) * 2] = gm.x0;
-            fgo[(frank - first_rank) * 2 + 1] = gm.y0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int xx = fgo[g * 2] + (tq & 1), yy = fgo[g * 2 + 1] + (tq >> 1);
-        const bool ok = g < have && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
-        const unsigned go = ok ? (unsigned)(LS[l] + yy * W + xx) * kGPixB + (unsigned)tp * 16u : 0x80000000u;
-        const u32x4 pre = __builtin_amdgcn_raw_buffer_load_b128(rsrc, go, 0, 0);
-        *reinterpret_cast<u32x4 *>(wreg + kWnPatchTop + g * 128 + (tq & 1) * 64 + (tq >> 1) * (int)kWnPitchB + tp * 16) = pre;
-    };
-    auto setup = [&](int l, int t, const WinSamples &sm) {
-        const int *dsc = desc_tab + (t & (kWnRing - 1)) * 16 + l * 4;
-        const int wx0 = __builtin_amdgcn_readfirstlane(dsc[0]);
-        const int wy0 = __builtin_amdgcn_readfirstlane(dsc[1]);
         const unsigned buf = l < 2 ? (unsigned)kWnBufAOff : (unsigned)kWnBufBOff;
-        const Geo gm = geometry(l, t, sm);
-        const float hx = 1.f - gm.lx, hy = 1.f - gm.ly, a = sm.a[l];
+        const float x = sxy.x * (float)W - 0.5f;
+        const float y = sxy.y * (float)H - 0.5f;
+        const bool inside = qok && (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);      // false for NaN
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = inside ? (int)xf : 0, y0 = inside ? (int)yf : 0;       // in [-1, size - 1]
+        const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
         // corners outside the level read zeros (window border / range-checked patch loads): no per-corner masks
-        const float w00 = gm.inside ? hy * hx * a : 0.f, w01 = gm.inside ? hy * gm.lx * a : 0.f;
-        const float w10 = gm.inside ? gm.ly * hx * a : 0.f, w11 = gm.inside ? gm.ly * gm.lx * a : 0.f;
-        const bool flagged = gm.inside && !gm.in_win;
+        const float w00 = inside ? hy * hx * a : 0.f, w01 = inside ? hy * lx * a : 0.f;
+        const float w10 = inside ? ly * hx * a : 0.f, w11 = inside ? ly * lx * a : 0.f;
+        const int cx = x0 - wx0, cy = y0 - wy0;
+        const bool in_win = (unsigned)cx < (unsigned)(kWnWinW - 1) && (unsigned)cy < (unsigned)(rh - 1);
+        const bool flagged = inside && !in_win;
         const unsigned long long fmask0 = __ballot(flagged);
-        const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask0, 0));
-        unsigned o = lds0 + (unsigned)kWnZeroOff + par32;                     // not inside, or flagged beyond the first four
-        if (gm.inside && gm.in_win)
-            o = lds0 + buf + (unsigned)(gm.y0 - wy0) * kWnPitchB + (unsigned)(gm.x0 - wx0) * kWnPixB + par32;
-        if (flagged && frank < 4) o = lds0 + wave_off + (unsigned)kWnPatchTop + (unsigned)frank * 128u + par32;
+        Staged st;
+        const int frank = flagged ? __builtin_amdgcn_mbcnt_hi((unsigned)(fmask0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask0, 0)) : -1;
         const int nflag = __builtin_popcountll(fmask0);                       // uniform
-        if (nflag) patch_rows(l, gm, flagged, frank, 0, nflag);
-        unsigned h01, h23, l01, l23;
-        wn_split2(w00, w01, h01, l01);
-        wn_split2(w10, w11, h23, l23);
-        reinterpret_cast<unsigned *>(wreg + kWnStageO)[qx * 4 + pp] = o;                          // O[query][point]
-        {
-            u32x2 *sw = reinterpret_cast<u32x2 *>(wreg + kWnStageW + qx * 64 + pp * 8);           // W[query][part][point][corner]
-            sw[0] = u32x2{h01, h23};
-            sw[4] = u32x2{l01, l23};
+        const unsigned pk = ((unsigned)(y0 + 1) << 15) | (unsigned)(x0 + 1);  // levels up to 32766 pixels a side (checked on the host)
+        st.o = lds0 + (unsigned)kWnZeroOff + par32;                           // a sample outside the level: the zero sample
+        if (inside && in_win) st.o = lds0 + buf + (unsigned)cy * kWnPitchB + (unsigned)cx * kWnPixB + par32;
+        const unsigned pbase = lds0 + slot_off(s) + (unsigned)(kWnPatch + pbuf * 1024);
+        if (flagged) st.o = frank < 4 ? 0x80000000u | (pbase + (unsigned)frank * 256u + par32) : 0xC0000000u | pk;
+        if (nflag) {
+            // the rows of the first four flagged samples go straight to the idle patch buffer by LDS-DMA (no registers; retired
+            // with the window fills before the barrier that ends the pass)
+            const unsigned go = patch_offset(l, s, pk, frank, 0, nflag);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(pbase);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                         :
+                         : "s"(m0v), "v"(go), "s"(rsrc)
+                         : "memory", "m0");
         }
-        return nflag;
+        wn_split2(w00, w01, st.h01, st.l01);
+        wn_split2(w10, w11, st.h23, st.l23);
+        return st;
+    };
+    // end of a pass: the staged set-up of the next one goes to LDS (O, W) -- the gather that read the old staging is done
+    auto stage = [&](const Staged &st, int s) {
+        unsigned char *reg = lds + slot_off(s);
+        reinterpret_cast<unsigned *>(reg + kWnStageO)[qx * 4 + pp] = st.o;                        // O[query][point]
+        u32x2 *sw = reinterpret_cast<u32x2 *>(reg + kWnStageW + qx * 64 + pp * 8);                // W[query][part][point][corner]
+        sw[0] = u32x2{st.h01, st.h23};
+        sw[4] = u32x2{st.l01, st.l23};
     };
 
-    // gather: the MFMA loop over the staged samples -- per (octet, quad half) one 16-byte read brings the top-left offsets
-    // of all four points, then two steps
-    auto gather = [&](int l, int t, const WinSamples &sm, int nflag) {
+    // gather: the MFMA loop over the staged samples of slot s -- per (octet, quad half) one 16-byte read brings the top-left
+    // offsets of all four points, then two steps
+    auto gather = [&](int l, int s, int pbuf) {
+        const unsigned zsample = lds0 + (unsigned)kWnZeroOff + (unsigned)(g & 1) * 32u + cd;
+        auto row = [&](unsigned o) {
+            return (int)o >= 0 ? o + cd : ((o & 0x40000000u) ? zsample : (o & 0x3fffffffu) + cdp);
+        };
+        const unsigned sbase = lds0 + slot_off(s);
+        const unsigned o_rd = sbase + (unsigned)kWnStageO + (unsigned)g * 16u;                    // + (8 o' + 4 h) * 16
+        const unsigned w_rd0 = a_live0 ? sbase + w_lane : lds0 + (unsigned)kWnZeroKOff;
+        const unsigned w_rd1 = a_live1 ? sbase + w_lane : lds0 + (unsigned)kWnZeroKOff;
         if (!(dbg & 32))
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
@@ -510,23 +552,25 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
             for (int h = 0; h < 2; ++h) {
                 const u32x4 so = lds_b128(o_rd + (unsigned)(8 * op + 4 * h) * 16u);
                 const unsigned wa = (h ? w_rd1 : w_rd0) + op * 512;
-                mfma_step(wa, so.x + cd, so.y + cd, acc[op][0], acc[op][1]);
-                mfma_step(wa + 16, so.z + cd, so.w + cd, acc[op][0], acc[op][1]);
+                mfma_step(wa, row(so.x), row(so.y), acc[s][op][0], acc[s][op][1]);
+                mfma_step(wa + 16, row(so.z), row(so.w), acc[s][op][0], acc[s][op][1]);
             }
         }
-        // more than four flagged samples (rare): four at a time through the patch, one MFMA step per sample with every
-        // other row of the operand pointing at the zero sample
-        if (nflag > 4) {
-            const Geo gm = geometry(l, t, sm);
-            const bool flagged = gm.inside && !gm.in_win;
-            unsigned long long fmask = __ballot(flagged);
-            const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0));
-            for (int k = 0; k < 4; ++k) fmask &= fmask - 1;          // the first four went through the loop above
-            int done = 4;
+        // more than four flagged samples (rare): the others four at a time through the (now consumed) patch buffer, one MFMA
+        // step per sample with every other row of the operand pointing at the zero sample
+        const unsigned myo = reinterpret_cast<const unsigned *>(lds + slot_off(s) + kWnStageO)[qx * 4 + pp];     // as set-up lane
+        const bool overflow = (myo >> 30) == 3u;
+        unsigned long long fmask = __ballot(overflow);
+        if (fmask != 0ull) {
+            const int frank = overflow ? __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0)) : -1;
+            const int nflag = __builtin_popcountll(fmask);
+            const unsigned xy = myo & 0x3fffffffu;
+            int done = 0;
             while (fmask != 0ull) {                                  // uniform
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                patch_rows(l, gm, flagged, frank, done, nflag - done);
+                const u32x4 pre = __builtin_amdgcn_raw_buffer_load_b128(rsrc, patch_offset(l, s, xy, frank, done, nflag - done), 0, 0);
+                *reinterpret_cast<u32x4 *>(lds + slot_off(s) + kWnPatch + pbuf * 1024 + lane * 16) = pre;     // [sample g][corner tq][chunk tp]
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -537,46 +581,49 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
                     fmask &= fmask - 1;
                     const int fq = id >> 2, fp = id & 3;               // its step: octet fq >> 3, quad half (fq >> 2) & 1, pair fp >> 1
                     const unsigned gp32 = (unsigned)(g & 1) * 32u;
-                    const unsigned zr = lds0 + (unsigned)kWnZeroOff + gp32 + cd;
-                    const unsigned prow = lds0 + wave_off + (unsigned)kWnPatchTop + (unsigned)k * 128u + gp32 + cd;
+                    const unsigned zr = zsample;
+                    const unsigned prow = sbase + (unsigned)(kWnPatch + pbuf * 1024) + (unsigned)k * 256u + gp32 + cdp;
                     const unsigned oa = (g == (fq & 3) && !(fp & 1)) ? prow : zr;
                     const unsigned ob = (g == (fq & 3) && (fp & 1)) ? prow : zr;
                     const unsigned wa = ((fq & 4) ? w_rd1 : w_rd0) + (unsigned)((fp >> 1) * 16);
-                    if (fq < 8) mfma_step(wa, oa, ob, acc[0][0], acc[0][1]);
-                    else mfma_step(wa + 512, oa, ob, acc[1][0], acc[1][1]);
+                    if (fq < 8) mfma_step(wa, oa, ob, acc[s][0][0], acc[s][0][1]);
+                    else mfma_step(wa + 512, oa, ob, acc[s][1][0], acc[s][1][1]);
                 }
                 done += 4;
             }
         }
     };
 
-    // out[query][channel] = D[hi row] + D[lo row]; transposed through the wave's region so that a lane stores 16 bytes
-    auto store_tile = [&](int sq) {
-        float *tr = reinterpret_cast<float *>(wreg);
+    // out[query][channel] = D[hi row] + D[lo row]; transposed through the slot's W area (dead after the last gather of the
+    // tile), one octet at a time, so that a lane stores 16 bytes
+    auto store_tile = [&](int sq, int s) {
+        float *tr = reinterpret_cast<float *>(lds + slot_off(s) + kWnStageW);     // 1 KiB: 8 queries x 32 channels
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
-                const f32x4 d = acc[op][X];
-                tr[(8 * op + 2 * g) * 32 + (lane & 15) + 16 * X] = d.x + d.y;
-                tr[(8 * op + 2 * g + 1) * 32 + (lane & 15) + 16 * (X ^ 1)] = d.z + d.w;
+                const f32x4 d = acc[s][op][X];
+                tr[(2 * g) * 32 + (lane & 15) + 16 * X] = d.x + d.y;
+                tr[(2 * g + 1) * 32 + (lane & 15) + 16 * (X ^ 1)] = d.z + d.w;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // lane (qx, pp) stores channels 8 pp .. 8 pp + 7 of query qx: the octet's queries are qx = 8 op .. 8 op + 7
+            const int ql = qx & 7;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(tr + ql * 32 + pp * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(tr + ql * 32 + pp * 8 + 4);
+            if (sq >= 0 && (qx >> 3) == op) {
+                u32x4 w;
+                w.x = pack_bf16x2(lo.x, lo.y);
+                w.y = pack_bf16x2(lo.z, lo.w);
+                w.z = pack_bf16x2(hi.x, hi.y);
+                w.w = pack_bf16x2(hi.z, hi.w);
+                *reinterpret_cast<u32x4 *>(out + ((size_t)b * Nq + sq) * (kWnHeads * kWnHeadDim) + m * kWnHeadDim + pp * 8) = w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const f32x4 lo = *reinterpret_cast<const f32x4 *>(tr + qx * 32 + pp * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4 *>(tr + qx * 32 + pp * 8 + 4);
-        if (sq >= 0) {
-            u32x4 w;
-            w.x = pack_bf16x2(lo.x, lo.y);
-            w.y = pack_bf16x2(lo.z, lo.w);
-            w.z = pack_bf16x2(hi.x, hi.y);
-            w.w = pack_bf16x2(hi.z, hi.w);
-            *reinterpret_cast<u32x4 *>(out + ((size_t)b * Nq + sq) * (kWnHeads * kWnHeadDim) + m * kWnHeadDim + pp * 8) = w;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     };
 
     // ---- pipeline ----------------------------------------------------------------------------------------------
@@ -590,81 +637,80 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     };
     if (tid < kWnRing * 16) tables_for(t0 + (tid >> 4), tid & 15);
     __syncthreads();
-    WinSamples cur;                        // the current tile's samples; the next tile's are loaded in pass 3 (below)
-    load_samples(t0, cur);
+    WinSamples cur[kWnSlotsPerWave], nxt[kWnSlotsPerWave];   // this tile's samples / the next tile's (loaded a tile ahead)
+    Staged sn[kWnSlotsPerWave];                              // the staged set-up of the coming pass
+    f32x4 nrf[kWnSlotsPerWave];                              // FUSED: raw reference points of the tile being loaded
+    fill(0, t0);
 #pragma unroll
-    for (int l = 0; l < kWnLevels; ++l) asm volatile("" ::"v"(cur.xy[l].x), "v"(cur.xy[l].y), "v"(cur.a[l]));   // retire the loads
-    fill(0, t0, wave, kWnWaves);
+    for (int s = 0; s < kWnSlotsPerWave; ++s) {
+        nrf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load_samples(t0, s, cur[s], nrf[s]);
+        finalize(cur[s], nrf[s]);
+        sn[s] = setup(0, t0, s, cur[s].xy[0], cur[s].a[0], cur[s].q >= 0, 0);       // set-up of the first pass
+        stage(sn[s], s);
+        nxt[s] = cur[s];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     wn_dma_wait();
     __syncthreads();
 
-    // Half-phases.  A pass (one sampled level) is setup | barrier | gather | barrier, and the two halves of the workgroup
-    // run it ONE HALF-PHASE APART: while waves 0..7 gather (LDS reads + MFMA) waves 8..15 set up (VALU) and vice versa --
-    // in lockstep the two pipes took turns (measured: set-up 27 us + gather 46 us of a 142-us kernel, nothing overlapping).
-    // Every wave executes the same sequence; the late half just starts one barrier later and ends one barrier earlier.
-    //   window of pass P: read in half-phases 2P + 1 (early half) and 2P + 2 (late half); its buffer is re-filled for pass
-    //   P + 2 from half-phase 2P + 3 on: the LATE half issues that fill at the start of its set-up of pass P + 1 and
-    //   retires it before the barrier that ends its gather of pass P + 1 (two half-phases to land).  The early half never
-    //   has DMA in flight, so its location loads cross barriers freely.
-    const bool late = wave >= kWnWaves / 2;
-    auto hp_barrier = [&](bool retire_dma) {
-        if (retire_dma) wn_dma_wait();
-        __syncthreads();
-    };
-    if (late) hp_barrier(false);
-
-    // levels in pass order, and the window that is filled while pass p is worked on (level, tile offset)
+    const bool gather_first = wave < kWnWaves / 2;           // waves w and w + 4 share a SIMD: opposite orders
+    if (dbg & 64) return;
     for (int t = t0; t < t1; ++t) {
         const bool has_next = t + 1 < t1;
-        const bool busy = __ballot(cur.q >= 0) != 0ull;  // any query in this wave?
+        bool busy[kWnSlotsPerWave];
 #pragma unroll
-        for (int op = 0; op < 2; ++op)
+        for (int s = 0; s < kWnSlotsPerWave; ++s) {
+            busy[s] = __ballot(cur[s].q >= 0) != 0ull;       // any query in this slot?
 #pragma unroll
-            for (int X = 0; X < 2; ++X) acc[op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int sq = cur.q;
-        f32x2 nxy3 = {0.f, 0.f};           // next tile: level 3 of its samples (levels 0..2 are loaded into `cur` in place)
-        float na3 = 0.f;
-        int nq = -1;
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int X = 0; X < 2; ++X) acc[s][op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
-        auto one_pass = [&](int p, int l, int fl, int ft, bool do_fill) {
-            // early half: [setup] barrier [gather] barrier;   late half: [issue fill, setup] barrier [gather | retire fill] barrier
-            int nflag = 0;
-            if (late && do_fill && !(dbg & 2)) fill(fl, ft, wave - kWnWaves / 2, kWnWaves / 2);
-            if (busy && !(dbg & 4)) nflag = setup(l, t, cur);
-            if (p == 3 && has_next && !(dbg & 16)) {
-                // the last set-up of the tile has consumed levels 0..2 of `cur`: fetch the next tile's samples behind the gather
-                WinSamples nx;
-                load_samples(t + 1, nx);
+        // pass p: gather level l from its window | set up level ln of tile tn (the next pass) | window (fl, ft) -> the idle buffer
+        auto one_pass = [&](int p, int l, int ln, int tn, bool do_setup, int fl, int ft, bool do_fill) {
+            if (do_fill && !(dbg & 2)) fill(fl, ft);
+            if (p == 0 && has_next && !(dbg & 16)) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { cur.xy[k] = nx.xy[k]; cur.a[k] = nx.a[k]; }
-                nxy3 = nx.xy[3]; na3 = nx.a[3]; nq = nx.q;
+                for (int s = 0; s < kWnSlotsPerWave; ++s) load_samples(t + 1, s, nxt[s], nrf[s]);     // land during passes 0 .. 2
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // staging is private to the wave: wave-level ordering suffices
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            hp_barrier(false);
-            if (busy && !(dbg & 4)) gather(l, t, cur, nflag);
-            if (p == 3) {
-                if (busy && !(dbg & 8)) store_tile(sq);
-                if (has_next && !(dbg & 16)) {
-                    cur.xy[3] = nxy3; cur.a[3] = na3; cur.q = nq;
-                    // make the compiler retire the location loads HERE (it waits lazily, at the first use -- which would
-                    // be inside the next set-up, behind untracked DMA, and would drain it)
+            if (p == 3 && has_next) {
 #pragma unroll
-                    for (int k = 0; k < kWnLevels; ++k) asm volatile("" ::"v"(cur.xy[k].x), "v"(cur.xy[k].y), "v"(cur.a[k]));
+                for (int s = 0; s < kWnSlotsPerWave; ++s) finalize(nxt[s], nrf[s]);
+            }
+#pragma unroll 1
+            for (int k = 0; k < 2; ++k) {                  // the two waves of a SIMD in opposite order
+                if ((k == 0) == gather_first) {
+#pragma unroll
+                    for (int s = 0; s < kWnSlotsPerWave; ++s)
+                        if (busy[s] && !(dbg & 4)) gather(l, s, p & 1);
+                } else if (do_setup && !(dbg & 4)) {
+#pragma unroll
+                    for (int s = 0; s < kWnSlotsPerWave; ++s) {
+                        const WinSamples &sm = p == 3 ? nxt[s] : cur[s];
+                        sn[s] = setup(ln, tn, s, sm.xy[ln], sm.a[ln], sm.q >= 0, (p + 1) & 1);
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads before the next pass's staging writes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the gather's reads of the staging before the new staging
             __builtin_amdgcn_wave_barrier();
-            hp_barrier(late);
+#pragma unroll
+            for (int s = 0; s < kWnSlotsPerWave; ++s) {
+                if (p == 3 && busy[s] && !(dbg & 8)) store_tile(cur[s].q, s);
+                if (do_setup && !(dbg & 4)) stage(sn[s], s);
+                if (p == 3 && has_next) cur[s] = nxt[s];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            wn_dma_wait();
+            __syncthreads();
         };
-        one_pass(0, 0, 2, t, true);                  // level 0 from A | level 2 -> B
-        one_pass(1, 2, 1, t, true);                  // level 2 from B | level 1 -> A
-        if (t > t0 && ((t - t0) & 7) == 0 && tid < 128) tables_for(t + 8 + (tid >> 4), tid & 15);      // entries of tiles t - 8 .. t - 1 are dead
-        one_pass(2, 1, 3, t, true);                  // level 1 from A | level 3 -> B
-        one_pass(3, 3, 0, t + 1, has_next);          // level 3 from B | next tile's level 0 -> A
+        one_pass(0, 0, 2, t, true, 2, t, true);                         // level 0 from A | set up level 2 | level 2 -> B
+        one_pass(1, 2, 1, t, true, 1, t, true);                         // level 2 from B | set up level 1 | level 1 -> A
+        if (t > t0 && ((t - t0) & 7) == 0 && tid < 128 && !(dbg & 128)) tables_for(t + 8 + (tid >> 4), tid & 15);      // entries of tiles t - 8 .. t - 1 are dead
+        one_pass(2, 1, 3, t, true, 3, t, true);                         // level 1 from A | set up level 3 | level 3 -> B
+        one_pass(3, 3, 0, t + 1, has_next, 0, t + 1, has_next);         // level 3 from B | next tile's level 0 | its window -> A
     }
-    if (!late) hp_barrier(false);
 }
 
 #ifdef RDETR_DEV

@@ -7,7 +7,7 @@
 // 3.5x that rate, and a spatial tile of queries re-uses every row it stages about six times.
 //
 //   tile      a 16 x 12 pixel region of level 0 plus the pixels of the coarser levels whose centres fall into it
-//             (<= 192 + 64 queries); slots 0..11 own the region's rows, slots 12..15 its coarser pixels.
+//             (<= 192 + 64 queries); waves 0..11 own the region's rows, waves 12..15 its coarser pixels.
 //   windows   per tile and sampled level a 32-pixel-wide window of the (image, head) value plane around the tile's
 //             footprint in that level (28 rows for levels 0 / 1, 19 for levels 2 / 3), IN PADDED COORDINATES: the window
 //             may start at pixel -1 and end at pixel W, and whatever lies outside the level arrives as zeros -- the
@@ -28,13 +28,15 @@
 //             fp32 weights (w = hi + lo to 2^-17, products exact, fp32 accumulate); D rows of one lane add up to a
 //             query's channels.  One MFMA serves 8 samples x 16 channels.
 //   flagged   nothing is assumed about the sampling locations.  A sample whose corners are not all inside its window
-//             gets its four rows fetched by range-checked loads into a per-wave LDS patch laid out like a piece of
-//             window (same corner constants) BEFORE the MFMA loop, so the loop is the same 8 steps whatever the
-//             locations; more than four such samples per wave and level take extra steps (a decoder-like scatter
-//             merely runs slowly).  The result never depends on the windows.
+//             gets its four rows fetched by range-checked LDS-DMA into a patch cell laid out like a piece of window
+//             (same corner constants: the patch cells form a pseudo-window of their own) while the previous pass
+//             runs, so the MFMA loop is the same 8 steps whatever the locations; more than four such samples per
+//             wave and level take extra steps (a decoder-like scatter merely runs slowly).  The result never depends
+//             on the windows.
 //
-//   workgroup = 512 threads = 8 waves with TWO 16-query slots each (256 registers per lane: the set-up of one pass and the
-//               gather of another are live together), persistent over a contiguous range of the tiles of ONE (image, head).
+//   workgroup = 1024 threads = 16 waves (one 16-query group each; a wave issues one instruction per ~5 clocks whatever
+//               its instruction-level parallelism, so it takes four waves per SIMD to keep the vector ALU busy), persistent
+//               over a contiguous range of the tiles of ONE (image, head).
 //   passes    = one per sampled level, order L0 (A), L2 (B), L1 (A), L3 (B): the two window buffers alternate, the fill of
 //               the next pass is issued at the top of the current one; one barrier per pass.  A pass GATHERS its level
 //               (LDS reads + MFMA) and SETS UP the next pass (VALU; results kept in registers, staged to LDS at the end):
@@ -53,23 +55,21 @@ typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
 typedef short wn_s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWnThreads = 512;
-constexpr int kWnWaves = kWnThreads / kWave;                  // 8
-constexpr int kWnSlotsPerWave = 2;
-constexpr int kWnSlots = kWnWaves * kWnSlotsPerWave;          // 16 groups of 16 queries per tile
-constexpr int kWnRegW = 16, kWnRegH = 12;                     // level-0 pixels of a spatial tile: one row per slot 0..11
-constexpr int kWnCoarseSlot0 = kWnRegH;                       // slots 12..15: the region's coarser-level queries
-constexpr int kWnCoarseSlots = (kWnSlots - kWnCoarseSlot0) * 16;
+constexpr int kWnThreads = 1024;
+constexpr int kWnWaves = kWnThreads / kWave;                  // 16 = groups of 16 queries per tile, one per wave
+constexpr int kWnRegW = 16, kWnRegH = 12;                     // level-0 pixels of a spatial tile: one row per wave 0..11
+constexpr int kWnCoarseWave0 = kWnRegH;                       // waves 12..15: the region's coarser-level queries
+constexpr int kWnCoarseSlots = (kWnWaves - kWnCoarseWave0) * 16;
 constexpr int kWnHeads = 8, kWnHeadDim = 32, kWnPoints = 4, kWnLevels = 4;
 constexpr unsigned kWnPixB = 64;                              // LDS bytes per pixel (one bf16 head row)
 constexpr int kWnWinW = 32;                                   // window width in pixels = two DMA instructions per row
 constexpr unsigned kWnPitchB = (kWnWinW + 2) * kWnPixB;       // 2176 B: == 128 (mod 256)
-constexpr int kWnRowsA = 28, kWnRowsB = 19;                   // window rows: buffer A (levels 0 / 1), buffer B (levels 2 / 3)
+constexpr int kWnRowsA = 27, kWnRowsB = 18;                   // window rows: buffer A (levels 0 / 1), buffer B (levels 2 / 3)
 constexpr int kWnMargin = 8;                                  // rows / columns of margin around a footprint
 constexpr int kWnRing = 16;                                   // tiles whose geometry / window tables are kept (ring)
 
 // ---- LDS map ------------------------------------------------------------------------------------------------------
-constexpr int kWnFgoOff = 512;                                // 16 slots x 64 B: pixel coordinates of the flagged samples in flight
+constexpr int kWnFgoOff = 512;                                // 16 waves x 64 B: [0..3] pixels of the flagged samples in flight, [8] overflow flag
 constexpr int kWnGeoOff = 1536;                               // int geo[kWnRing][20]
 constexpr int kWnDescOff = kWnGeoOff + kWnRing * 80;          // int desc[kWnRing][4 levels][4]
 constexpr int kWnZeroOff = 4096;                              // 1 KiB of zeros: idle A-operand lanes; its first 128 B = the
@@ -78,19 +78,22 @@ constexpr int kWnZeroBotOff = kWnZeroOff + (int)kWnPitchB;    // 128 B of zeros 
 constexpr int kWnZeroKOff = kWnZeroOff + 128 + 32;            // what idle A lanes read; == 32 (mod 64) keeps it off the live lanes' banks
 constexpr int kWnMiscBytes = kWnZeroBotOff + 128;             // 6400
 static_assert(kWnDescOff + kWnRing * 64 <= kWnZeroOff, "tables overlap the zero block");
-// per-slot region: two patch buffers (the rows of up to four flagged samples each, 256 B per sample = four corners of 64 B;
-// one is read by the gather of pass p while the DMA for pass p + 1 lands in the other), then the staging
-constexpr int kWnSlotOff = kWnMiscBytes;
-constexpr int kWnPatch = 0;                                   // [0, 1024) buffer 0, [1024, 2048) buffer 1
-constexpr int kWnStageW = 2048;                               // [2048, 3072) W[query][part][point][corner] bf16
-constexpr int kWnStageO = 3072;                               // [3072, 3328) O[query][point] u32: LDS offset of the top-left corner;
-                                                              // bit 31 = a patch sample (corners 64 B apart instead of window-shaped)
-constexpr int kWnSlotBytes = 3328;
-constexpr int kWnBufAOff = kWnSlotOff + kWnSlots * kWnSlotBytes;
+// per-wave staging
+constexpr int kWnWaveOff = kWnMiscBytes;
+constexpr int kWnStageW = 0;                                  // [0, 1024)    W[query][part][point][corner] bf16
+constexpr int kWnStageO = 1024;                               // [1024, 1280) O[query][point] u32: LDS offset of the sample's top-left corner
+constexpr int kWnStageV = 1280;                               // [1280, 1536) overflow list: per set-up lane, bit 31 | top-left pixel, or 0
+constexpr int kWnWaveBytes = 1536;
+// patch cells: the rows of the flagged samples, WINDOW-SHAPED -- a sample's top corners side by side (128 B), its bottom
+// corners one window pitch further on -- so that window, patch and zero samples share the corner constants.  A cell =
+// four samples = 512 B of one row + 512 B of the next; four cells per row pair, two cells (passes p, p + 1) per wave
+constexpr int kWnPatchOff = kWnWaveOff + kWnWaves * kWnWaveBytes;
+constexpr int kWnPatchBytes = (2 * kWnWaves / 4) * 2 * (int)kWnPitchB;
+constexpr int kWnBufAOff = kWnPatchOff + kWnPatchBytes;
 constexpr int kWnBufBOff = kWnBufAOff + kWnRowsA * (int)kWnPitchB;
 constexpr int kWnLdsBytes = kWnBufBOff + kWnRowsB * (int)kWnPitchB;
 static_assert(kWnLdsBytes <= 160 * 1024, "LDS map exceeds 160 KiB");
-static_assert(kWnSlotBytes % 256 == 0 && kWnBufAOff % 256 == 0, "window buffers must keep the bank phase of the pitch");
+static_assert(kWnPatchOff % 256 == 0 && kWnBufAOff % 256 == 0, "window-shaped areas must keep the bank phase of the pitch");
 
 struct WinShared {
     int h[kWnLevels], w[kWnLevels], start[kWnLevels];
@@ -101,12 +104,6 @@ static_assert(sizeof(WinShared) <= kWnFgoOff, "tables overlap");
 // ring tables (kWnGeoOff / kWnDescOff), entry = tile & (kWnRing - 1):
 //   geo[20]      rx, ry, chunk, -, then per coarser level: xa, ya, nx, n, 2^16 / nx
 //   desc[4][4]   per level: window origin x, y in pixel coordinates (>= -1), rows, -
-
-struct WinSamples {                        // lane (query = lane >> 2, point = lane & 3): its sample in each level
-    f32x2 xy[kWnLevels];                   // FUSED, before finalize(): raw (offset x, offset y)
-    float a[kWnLevels];                    //                           raw attention logit
-    int q;                                 // query index of lane >> 2, -1 = none
-};
 
 __device__ __forceinline__ float wn_quad_max(float v)
 {
@@ -156,8 +153,21 @@ __device__ __forceinline__ void wn_split2(float a, float b, unsigned &hi, unsign
     lo = __builtin_bit_cast(unsigned, wn_bf16x2{(__bf16)ra, (__bf16)rb});
 }
 
+// A copy of `v` the optimiser cannot see through: address arithmetic derived from it is redone where it is used instead of
+// being hoisted out of the tile loop as yet another long-lived register (the kernel runs at the 128-register limit of a
+// 1024-thread workgroup; a spilled loop invariant costs a memory round trip per tile)
+__device__ __forceinline__ int wn_opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // retire this wave's LDS-DMA before the barrier that publishes the buffers (the compiler does not know about it)
 __device__ __forceinline__ void wn_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... when the wave's two youngest vector-memory operations are the tile's output stores (vmcnt counts in issue order, stores
+// included): the DMA is retired, the stores stay in flight across the barrier instead of holding the whole workgroup for
+// their round trip to memory
+__device__ __forceinline__ void wn_dma_wait_keep2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 
 // HM = false: value [B,S,H,D] (pixel-major, the reference operator's layout); HM = true: value [B,H,S,D] (head-major).
 template <bool FUSED, bool HM>
@@ -242,24 +252,33 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(plane), 0, plane_bytes, 0x00020000);
 
-    // set-up role: query qx of the slot, point pp.   gather role: K-group g, corner tq / piece tp of a transposed read;
+    // set-up role: query qx of the wave, point pp.   gather role: K-group g, corner tq / piece tp of a transposed read;
     // as an A-operand lane: row am = lane & 15 = 8 * (quad half ah) + 2 * (K-group ag) + (0 = bf16 high part, 1 = low part)
     const int qx = lane >> 2, pp = lane & 3;
     const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
     const int am = lane & 15, ah = am >> 3, ag = (am >> 1) & 3, apart = am & 1;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;     // 0 in practice
-    // slot s of this wave = group 2 * wave + s of the tile's 16 groups of 16 queries; its LDS region:
-    auto slot_off = [&](int s) { return (unsigned)(kWnSlotOff + (kWnSlotsPerWave * wave + s) * kWnSlotBytes); };     // scalar
+    const unsigned wave_off = (unsigned)(kWnWaveOff + wave * kWnWaveBytes);
+    unsigned char *wreg = lds + wave_off;
+    int *fgo = reinterpret_cast<int *>(lds + kWnFgoOff + wave * 64);
+    // patch cell of this wave for pass parity pb: its four samples' top corners; the bottom corners sit one pitch further on
+    auto cell_off = [&](int pb) {
+        const int c = 2 * wave + pb;
+        return (unsigned)(kWnPatchOff + (c >> 2) * 2 * (int)kWnPitchB + (c & 3) * 512);
+    };
     // One MFMA step = octet o', quad half h, point pair j: K-group g carries the two samples (points 2j, 2j + 1) of
-    // query 8 o' + 4 h + g; its lane (corner tq, piece tp) reads row `top-left + cd` of each.
+    // query 8 o' + 4 h + g; its lane (corner tq, piece tp) reads row `top-left + cd` of each -- window, patch and zero
+    // samples alike
     const unsigned cd = (unsigned)(tq & 1) * kWnPixB + (unsigned)(tq >> 1) * kWnPitchB + (unsigned)tp * 8u;
-    const unsigned cdp = (unsigned)tq * kWnPixB + (unsigned)tp * 8u;          // ... of a patch sample
+    const unsigned o_rd = lds0 + wave_off + (unsigned)kWnStageO + (unsigned)g * 16u;                   // + (8 o' + 4 h) * 16
     // A operand: lane (row am, K-group g) is live only in the steps of its own quad half and only if its row's query is the
     // K-group's -- then it reads that query's 2 x 4 weights (16 B); otherwise 16 B of zeros.  + o' * 512 + j * 16
-    const unsigned w_lane = (unsigned)kWnStageW + (unsigned)((4 * ah + g) * 64 + apart * 32);
-    const bool a_live0 = ag == g && ah == 0, a_live1 = ag == g && ah == 1;
+    const unsigned w_real = lds0 + wave_off + (unsigned)kWnStageW + (unsigned)((4 * ah + g) * 64 + apart * 32);
+    const unsigned w_rd0 = (ag == g && ah == 0) ? w_real : lds0 + (unsigned)kWnZeroKOff;
+    const unsigned w_rd1 = (ag == g && ah == 1) ? w_real : lds0 + (unsigned)kWnZeroKOff;
     const unsigned par32 = (unsigned)(qx & 1) * 32u;              // odd queries read the other channel half first: the two
                                                                   // K-groups of a 32-lane half never share a bank group
+    const unsigned o_zero = lds0 + (unsigned)kWnZeroOff + par32;  // the zero sample
 
     // ---- helpers -----------------------------------------------------------------------------------------------
     // Tile geometry (which region, and which pixels of the coarser levels have their centres in it) costs a dozen integer
@@ -282,17 +301,17 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         }
     };
 
-    // query owned by lane >> 2 of slot s in tile t (-1 = none)
-    auto query_of = [&](int t, int s) -> int {
-        const int grp = kWnSlotsPerWave * wave + s;
+    // query owned by lane >> 2 of this wave in tile t (-1 = none)
+    auto query_of = [&](int t) -> int {
+        const int qx = wn_opaque(lane) >> 2;
         const int *geo = geo_tab + (t & (kWnRing - 1)) * 20;
         const int rx = __builtin_amdgcn_readfirstlane(geo[0]), ry = __builtin_amdgcn_readfirstlane(geo[1]);
         const int chunk = __builtin_amdgcn_readfirstlane(geo[2]);
-        if (grp < kWnCoarseSlot0) {
-            const int x = rx * kWnRegW + qx, y = ry * kWnRegH + grp;
+        if (wave < kWnCoarseWave0) {
+            const int x = rx * kWnRegW + qx, y = ry * kWnRegH + wave;
             return (chunk == 0 && x < LW[0] && y < LH[0]) ? LS[0] + y * LW[0] + x : -1;
         }
-        int j = chunk * kWnCoarseSlots + (grp - kWnCoarseSlot0) * 16 + qx;
+        int j = chunk * kWnCoarseSlots + (wave - kWnCoarseWave0) * 16 + qx;
         int q = -1;
 #pragma unroll
         for (int l = 1; l < kWnLevels; ++l) {
@@ -310,75 +329,80 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         return q;
     };
 
-    // sampling locations / attention weights of this lane's (query, point) in every level: the LOADS only -- with FUSED the
-    // raw projection outputs, which finalize() turns into locations / weights once they have landed
-    auto load_samples = [&](int t, int s, WinSamples &sm, f32x4 &rf) {   // rf (FUSED): the reference point of level `lane & 3`
-        sm.q = query_of(t, s);
-        const size_t row = (size_t)b * Nq + (sm.q >= 0 ? sm.q : 0);
-        const size_t hrow = (row * kWnHeads + m) * (size_t)(kWnLevels * kWnPoints);
+    // ---- sample data: loaded ONE LEVEL AT A TIME, one pass before the set-up that consumes it --------------------------------
+    // !FUSED: (location, soft-maxed weight) of this lane's point in level l (the reference operator's inputs).
+    // FUSED : raw sampling offset of the point (packed bf16 x, y); the logits of all levels and the reference points are loaded
+    //         once per tile (tile_inputs), soft-maxed / applied in the set-up.
+    struct LevelData { f32x2 xy; float a; };               // FUSED: xy.x = the packed raw offsets (bits), a unused
+    auto load_level = [&](int q, int l) -> LevelData {
+        LevelData d;
+        const int pp = wn_opaque(lane) & 3;
+        const unsigned qq = (unsigned)(q >= 0 ? q : 0);
         if constexpr (FUSED) {
-            // row strides (elements) of the two projection outputs: they may be column slices of ONE [rows, 3*H*L*P] GEMM output
+            const size_t row = (size_t)b * Nq + qq;
             const uint16_t *off_q = static_cast<const uint16_t *>(src_a) +
-                                    (ld_a ? row * (size_t)ld_a + (size_t)m * (kWnLevels * kWnPoints * 2) : hrow * 2);
-            const uint16_t *lg_q = static_cast<const uint16_t *>(src_b) +
-                                   (ld_b ? row * (size_t)ld_b + (size_t)m * (kWnLevels * kWnPoints) : hrow);
-#pragma unroll
-            for (int l = 0; l < kWnLevels; ++l) {
-                const int pt = l * kWnPoints + pp;
-                sm.a[l] = bf16_bits_to_f32(lg_q[pt]);
-                const unsigned u = *reinterpret_cast<const unsigned *>(off_q + 2 * pt);
-                sm.xy[l] = f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
-            }
-            const float *rp = ref + (row * kWnLevels + pp) * (size_t)ref_dim;        // lane pp: the reference point of level pp
-            if (ref_dim == 2) {
-                const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
-                rf = f32x4{r2.x, r2.y, 0.f, 0.f};
-            } else {
-                rf = *reinterpret_cast<const f32x4 *>(rp);
-            }
+                                    (ld_a ? row * (size_t)ld_a + (size_t)m * (kWnLevels * kWnPoints * 2)
+                                          : (row * kWnHeads + m) * (size_t)(kWnLevels * kWnPoints * 2));
+            d.xy.x = __builtin_bit_cast(float, *reinterpret_cast<const unsigned *>(off_q + 2 * (l * kWnPoints + pp)));
+            d.xy.y = 0.f;
+            d.a = 0.f;
         } else {
             // 32-bit element offsets from the image's (uniform) base: B * Nq * 8 * 16 * 2 floats can exceed 2^32, one image cannot
             const float *loc_b = static_cast<const float *>(src_a) + (size_t)b * Nq * (kWnHeads * kWnLevels * kWnPoints * 2);
             const float *att_b = static_cast<const float *>(src_b) + (size_t)b * Nq * (kWnHeads * kWnLevels * kWnPoints);
-            const unsigned e = ((unsigned)(sm.q >= 0 ? sm.q : 0) * kWnHeads + (unsigned)m) * (kWnLevels * kWnPoints) + (unsigned)pp;
-#pragma unroll
-            for (int l = 0; l < kWnLevels; ++l) {
-                sm.xy[l] = *reinterpret_cast<const f32x2 *>(loc_b + 2u * (e + (unsigned)(l * kWnPoints)));
-                sm.a[l] = att_b[e + (unsigned)(l * kWnPoints)];
-            }
+            const unsigned e = (qq * kWnHeads + (unsigned)m) * (kWnLevels * kWnPoints) + (unsigned)(l * kWnPoints + pp);
+            d.xy = *reinterpret_cast<const f32x2 *>(loc_b + 2u * e);
+            d.a = att_b[e];
         }
+        return d;
     };
-    // FUSED: softmax over the L * P logits of a (query, head) and  loc = ref + off / (W, H)  |  ref_xy + off / P * ref_wh * 0.5
-    // (ms_deform_attn.py:326-349), in the reference's operation order
-    auto finalize = [&](WinSamples &sm, const f32x4 &rf) {
-        if constexpr (FUSED) {
-            float mx = fmaxf(fmaxf(sm.a[0], sm.a[1]), fmaxf(sm.a[2], sm.a[3]));
-            mx = wn_quad_max(mx);
-            float sum = 0.f;
+    struct TileInputs { float lg[kWnLevels]; f32x4 rf; };  // FUSED: raw logits of the lane's point in each level; reference point of level `pp`
+    auto load_tile_inputs = [&](int q) -> TileInputs {
+        TileInputs ti;
+        const int pp = wn_opaque(lane) & 3;
 #pragma unroll
-            for (int l = 0; l < kWnLevels; ++l) {
-                sm.a[l] = expf(sm.a[l] - mx);
-                sum += sm.a[l];
+        for (int l = 0; l < kWnLevels; ++l) ti.lg[l] = 0.f;
+        ti.rf = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FUSED) {
+            const size_t row = (size_t)b * Nq + (unsigned)(q >= 0 ? q : 0);
+            const uint16_t *lg_q = static_cast<const uint16_t *>(src_b) +
+                                   (ld_b ? row * (size_t)ld_b + (size_t)m * (kWnLevels * kWnPoints)
+                                         : (row * kWnHeads + m) * (size_t)(kWnLevels * kWnPoints));
+#pragma unroll
+            for (int l = 0; l < kWnLevels; ++l) ti.lg[l] = bf16_bits_to_f32(lg_q[l * kWnPoints + pp]);
+            const float *rp = ref + (row * kWnLevels + pp) * (size_t)ref_dim;        // lane pp: the reference point of level pp
+            if (ref_dim == 2) {
+                const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
+                ti.rf = f32x4{r2.x, r2.y, 0.f, 0.f};
+            } else {
+                ti.rf = *reinterpret_cast<const f32x4 *>(rp);
             }
-            sum = wn_quad_sum(sum);
-            auto level = [&](auto lc) {
-                constexpr int l = decltype(lc)::value;
-                const float rx = wn_quad_bcast<l>(rf.x), ry = wn_quad_bcast<l>(rf.y);
-                sm.a[l] = sm.a[l] / sum;
-                if (ref_dim == 2) {
-                    sm.xy[l].x = rx + sm.xy[l].x / (float)LW[l];
-                    sm.xy[l].y = ry + sm.xy[l].y / (float)LH[l];
-                } else {
-                    const float rw = wn_quad_bcast<l>(rf.z), rh = wn_quad_bcast<l>(rf.w);
-                    sm.xy[l].x = rx + sm.xy[l].x * (1.0f / kWnPoints) * rw * 0.5f;
-                    sm.xy[l].y = ry + sm.xy[l].y * (1.0f / kWnPoints) * rh * 0.5f;
-                }
-            };
-            level(std::integral_constant<int, 0>{});
-            level(std::integral_constant<int, 1>{});
-            level(std::integral_constant<int, 2>{});
-            level(std::integral_constant<int, 3>{});
         }
+        return ti;
+    };
+    // FUSED: softmax over the L * P logits of a (query, head) (ms_deform_attn.py:326-336) -> the four weights of this lane's point
+    auto softmax_levels = [&](const TileInputs &ti, float (&aw)[kWnLevels]) {
+        float mx = fmaxf(fmaxf(ti.lg[0], ti.lg[1]), fmaxf(ti.lg[2], ti.lg[3]));
+        mx = wn_quad_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < kWnLevels; ++l) {
+            aw[l] = expf(ti.lg[l] - mx);
+            sum += aw[l];
+        }
+        sum = wn_quad_sum(sum);
+#pragma unroll
+        for (int l = 0; l < kWnLevels; ++l) aw[l] = aw[l] / sum;
+    };
+    // FUSED: loc = ref + off / (W, H)  |  ref_xy + off / P * ref_wh * 0.5  (ms_deform_attn.py:339-349), the reference's operation order
+    auto fused_location = [&](auto lc, float packed, const f32x4 &rf) -> f32x2 {
+        constexpr int l = decltype(lc)::value;
+        const unsigned u = __builtin_bit_cast(unsigned, packed);
+        const float ox = __builtin_bit_cast(float, u << 16), oy = __builtin_bit_cast(float, u & 0xffff0000u);
+        const float rx = wn_quad_bcast<l>(rf.x), ry = wn_quad_bcast<l>(rf.y);
+        if (ref_dim == 2) return f32x2{rx + ox / (float)LW[l], ry + oy / (float)LH[l]};
+        const float rw = wn_quad_bcast<l>(rf.z), rh = wn_quad_bcast<l>(rf.w);
+        return f32x2{rx + ox * (1.0f / kWnPoints) * rw * 0.5f, ry + oy * (1.0f / kWnPoints) * rh * 0.5f};
     };
 
     // thread l: the window of level l for tile t -- 32 columns x (footprint + 2 * margin, at most the buffer's) rows centred
@@ -424,8 +448,9 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         const int rh = __builtin_amdgcn_readfirstlane(dsc[2]);
         const int W = LW[l], H = LH[l], st = LS[l];
         const unsigned buf = l < 2 ? (unsigned)kWnBufAOff : (unsigned)kWnBufBOff;
-        const int c0 = wx0 + (lane >> 2), c1 = c0 + 16;                       // this lane's column in either half
-        const unsigned chunk = (unsigned)(lane & 3) * 16u;
+        const int ln = wn_opaque(lane);
+        const int c0 = wx0 + (ln >> 2), c1 = c0 + 16;                         // this lane's column in either half
+        const unsigned chunk = (unsigned)(ln & 3) * 16u;
         const unsigned v0 = (c0 >= 0 && c0 < W) ? (unsigned)c0 * kGPixB + chunk : 0x80000000u;
         const unsigned v1 = (c1 >= 0 && c1 < W) ? (unsigned)c1 * kGPixB + chunk : 0x80000000u;
         const int n = 2 * rh;
@@ -443,7 +468,7 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         }
     };
 
-    f32x4 acc[kWnSlotsPerWave][2][2];      // [slot][octet o'][X]: D rows 4g + r of a lane = query 8 o' + 2g + (r >> 1), part r & 1,
+    f32x4 acc[2][2];                       // [octet o'][X]: D rows 4g + r of a lane = query 8 o' + 2g + (r >> 1), part r & 1,
                                            // channel (lane & 15) + 16 ((r >> 1) ^ X)
 
     auto lds_b128 = [](unsigned a) { return *(__attribute__((address_space(3))) const u32x4 *)a; };
@@ -460,30 +485,22 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wn_bf16x8, af), __builtin_bit_cast(wn_bf16x8, b1), d1, 0, 0, 0);
     };
 
-    // ---- one level of a slot's 16 queries: set-up into REGISTERS, staged to LDS at the end of the previous pass ---------
+    // ---- one level of the wave's 16 queries: set-up into REGISTERS, staged to LDS at the end of the previous pass -----------
     struct Staged {                        // what a lane carries from its set-up to the end of the pass
-        unsigned o, h01, h23, l01, l23;    // O entry (below); bf16 high / low parts of the four corner weights
+        unsigned o, h01, h23, l01, l23;    // LDS offset of the sample's top-left corner (bit 31 set: an OVERFLOW sample --
+    };                                     // flagged beyond the wave's first four -- and the low bits are its top-left pixel,
+                                           // (y0 + 1) << 15 | (x0 + 1)); bf16 high / low parts of the four corner weights
+    // top-left pixel `pk` -> this lane's byte offset in the value plane for corner (dx, dy), 16-byte chunk c
+    // (corners outside the level: out of range -> the load returns zeros and makes no request)
+    auto corner_offset = [&](int l, int pk, bool have, int dx, int dy, int c) -> unsigned {
+        const int xx = (pk & 0x7fff) - 1 + dx, yy = (pk >> 15) - 1 + dy;
+        const bool ok = have && (unsigned)xx < (unsigned)LW[l] && (unsigned)yy < (unsigned)LH[l];
+        return ok ? (unsigned)(LS[l] + yy * LW[l] + xx) * kGPixB + (unsigned)c * 16u : 0x80000000u;
     };
-    // O entry of a sample, by its two top bits:  0x = LDS offset of its top-left corner in a window (or of the zero sample);
-    // 10 = ... in a patch buffer (corners 64 B apart);  11 = flagged beyond the slot's first four ("overflow"): the low 30 bits
-    // are its top-left pixel ((y0 + 1) << 15 | (x0 + 1)), the main loop reads the zero sample and extra steps serve it
-    // flagged samples `first_rank .. first_rank + 3`: publish their pixel coordinates; -> this lane's (sample g, corner tq,
-    // 16-byte chunk tp) byte offset in the value plane (corners outside the level: out of range -> zeros, no request)
-    auto patch_offset = [&](int l, int s, unsigned pk, int frank, int first_rank, int have) -> unsigned {
-        const int W = LW[l], H = LH[l];
-        int *fgo = reinterpret_cast<int *>(lds + kWnFgoOff + (kWnSlotsPerWave * wave + s) * 64);
-        if (frank >= first_rank && frank < first_rank + 4) fgo[frank - first_rank] = (int)pk;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int pxy = fgo[g];
-        const int xx = (pxy & 0x7fff) - 1 + (tq & 1), yy = (pxy >> 15) - 1 + (tq >> 1);
-        const bool ok = g < have && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
-        return ok ? (unsigned)(LS[l] + yy * W + xx) * kGPixB + (unsigned)tp * 16u : 0x80000000u;
-    };
-    // set-up of this lane's sample (query qx, point pp) of slot s in level l of tile t: msda_fwd.hip's arithmetic
-    // (ms_deform_im2col_cuda.cuh:22-73); nothing is written to LDS except the flagged samples' coordinates
-    auto setup = [&](int l, int t, int s, f32x2 sxy, float a, bool qok, int pbuf) -> Staged {
+    // set-up of this lane's sample (query qx, point pp) in level l of tile t: msda_fwd.hip's arithmetic
+    // (ms_deform_im2col_cuda.cuh:22-73); writes nothing to LDS except the coordinates of the flagged samples, whose rows it
+    // sends on their way into patch cell `pb`
+    auto setup = [&](int l, int t, f32x2 sxy, float a, bool qok, int pb) -> Staged {
         const int *dsc = desc_tab + (t & (kWnRing - 1)) * 16 + l * 4;
         const int wx0 = __builtin_amdgcn_readfirstlane(dsc[0]);
         const int wy0 = __builtin_amdgcn_readfirstlane(dsc[1]);
@@ -502,75 +519,113 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
         const int cx = x0 - wx0, cy = y0 - wy0;
         const bool in_win = (unsigned)cx < (unsigned)(kWnWinW - 1) && (unsigned)cy < (unsigned)(rh - 1);
         const bool flagged = inside && !in_win;
-        const unsigned long long fmask0 = __ballot(flagged);
+        const unsigned long long fmask = __ballot(flagged);
         Staged st;
-        const int frank = flagged ? __builtin_amdgcn_mbcnt_hi((unsigned)(fmask0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask0, 0)) : -1;
-        const int nflag = __builtin_popcountll(fmask0);                       // uniform
-        const unsigned pk = ((unsigned)(y0 + 1) << 15) | (unsigned)(x0 + 1);  // levels up to 32766 pixels a side (checked on the host)
-        st.o = lds0 + (unsigned)kWnZeroOff + par32;                           // a sample outside the level: the zero sample
+        st.o = o_zero;                                                        // a sample outside the level: the zero sample
         if (inside && in_win) st.o = lds0 + buf + (unsigned)cy * kWnPitchB + (unsigned)cx * kWnPixB + par32;
-        const unsigned pbase = lds0 + slot_off(s) + (unsigned)(kWnPatch + pbuf * 1024);
-        if (flagged) st.o = frank < 4 ? 0x80000000u | (pbase + (unsigned)frank * 256u + par32) : 0xC0000000u | pk;
-        if (nflag) {
-            // the rows of the first four flagged samples go straight to the idle patch buffer by LDS-DMA (no registers; retired
-            // with the window fills before the barrier that ends the pass)
-            const unsigned go = patch_offset(l, s, pk, frank, 0, nflag);
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(pbase);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                         :
-                         : "s"(m0v), "v"(go), "s"(rsrc)
-                         : "memory", "m0");
+        if (fmask != 0ull) {                                                  // uniform
+            const int frank = __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0));
+            const int nflag = __builtin_popcountll(fmask);
+            const unsigned pk = ((unsigned)(y0 + 1) << 15) | (unsigned)(x0 + 1);          // levels up to 32766 pixels a side (host check)
+            const unsigned cell = lds0 + cell_off(pb);
+            if (flagged) st.o = frank < 4 ? cell + (unsigned)frank * 128u + par32 : 0x80000000u | pk;
+            if (flagged && frank < 4) fgo[frank] = (int)pk;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the rows of the first four flagged samples go straight into the patch cell by LDS-DMA (no registers; retired with
+            // the window fills before the barrier that ends the pass): lanes 0..31 the top corners (sample k, corner x, chunk),
+            // lanes 32..63 the bottom corners one pitch further on
+            const int lnp = wn_opaque(lane), pl = lnp & 31, k = pl >> 3;
+            const unsigned go = corner_offset(l, fgo[k], k < nflag, (pl >> 2) & 1, lnp >> 5, pl & 3);
+            const unsigned m0t = __builtin_amdgcn_readfirstlane(cell);
+            const unsigned m0b = __builtin_amdgcn_readfirstlane(cell + kWnPitchB - 512u);
+            if (lnp < 32) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             :
+                             : "s"(m0t), "v"(go), "s"(rsrc)
+                             : "memory", "m0");
+            } else {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             :
+                             : "s"(m0b), "v"(go), "s"(rsrc)
+                             : "memory", "m0");
+            }
         }
         wn_split2(w00, w01, st.h01, st.l01);
         wn_split2(w10, w11, st.h23, st.l23);
         return st;
     };
-    // end of a pass: the staged set-up of the next one goes to LDS (O, W) -- the gather that read the old staging is done
-    auto stage = [&](const Staged &st, int s) {
-        unsigned char *reg = lds + slot_off(s);
-        reinterpret_cast<unsigned *>(reg + kWnStageO)[qx * 4 + pp] = st.o;                        // O[query][point]
-        u32x2 *sw = reinterpret_cast<u32x2 *>(reg + kWnStageW + qx * 64 + pp * 8);                // W[query][part][point][corner]
+    // end of a pass: the staged set-up of the next one goes to LDS (O, W, overflow list) -- this wave's gather, which read the
+    // old staging, is done
+    auto stage = [&](const Staged &st) {
+        const int ln = wn_opaque(lane), qx = ln >> 2, pp = ln & 3;
+        unsigned char *wreg = lds + wave_off;
+        const bool overflow = (int)st.o < 0;
+        const bool any = __ballot(overflow) != 0ull;                          // uniform
+        reinterpret_cast<unsigned *>(wreg + kWnStageO)[qx * 4 + pp] = overflow ? o_zero : st.o;   // O[query][point]
+        u32x2 *sw = reinterpret_cast<u32x2 *>(wreg + kWnStageW + qx * 64 + pp * 8);              // W[query][part][point][corner]
         sw[0] = u32x2{st.h01, st.h23};
         sw[4] = u32x2{st.l01, st.l23};
+        if (any) reinterpret_cast<unsigned *>(wreg + kWnStageV)[ln] = overflow ? st.o : 0u;
+        if (ln == 0) fgo[8] = any ? 1 : 0;
     };
 
-    // gather: the MFMA loop over the staged samples of slot s -- per (octet, quad half) one 16-byte read brings the top-left
-    // offsets of all four points, then two steps
-    auto gather = [&](int l, int s, int pbuf) {
-        const unsigned zsample = lds0 + (unsigned)kWnZeroOff + (unsigned)(g & 1) * 32u + cd;
-        auto row = [&](unsigned o) {
-            return (int)o >= 0 ? o + cd : ((o & 0x40000000u) ? zsample : (o & 0x3fffffffu) + cdp);
-        };
-        const unsigned sbase = lds0 + slot_off(s);
-        const unsigned o_rd = sbase + (unsigned)kWnStageO + (unsigned)g * 16u;                    // + (8 o' + 4 h) * 16
-        const unsigned w_rd0 = a_live0 ? sbase + w_lane : lds0 + (unsigned)kWnZeroKOff;
-        const unsigned w_rd1 = a_live1 ? sbase + w_lane : lds0 + (unsigned)kWnZeroKOff;
-        if (!(dbg & 32))
-#pragma unroll
-        for (int op = 0; op < 2; ++op) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const u32x4 so = lds_b128(o_rd + (unsigned)(8 * op + 4 * h) * 16u);
-                const unsigned wa = (h ? w_rd1 : w_rd0) + op * 512;
-                mfma_step(wa, row(so.x), row(so.y), acc[s][op][0], acc[s][op][1]);
-                mfma_step(wa + 16, row(so.z), row(so.w), acc[s][op][0], acc[s][op][1]);
-            }
+    // gather: the MFMA loop over the staged samples -- per (octet, quad half) one 16-byte read brings the top-left offsets
+    // of all four points, then two steps
+    auto gather = [&](int l, int pb) {
+        if (!(dbg & 32)) {
+            // Software-pipelined by hand: all four offset reads first, then the operands of step s + 1 are on their way while
+            // the MFMAs of step s run (hipcc serialises read -> wait -> MFMA per step: twelve exposed LDS round trips per pass)
+            struct Operands { u32x4 af; u32x2 x0, x1, y0, y1; };
+            auto fetch = [&](unsigned wa, unsigned oa, unsigned ob) {
+                Operands r;
+                r.af = lds_b128(wa);
+                r.x0 = lds_tr(oa); r.x1 = lds_tr(ob); r.y0 = lds_tr(oa ^ 32u); r.y1 = lds_tr(ob ^ 32u);
+                return r;
+            };
+            auto fma2 = [&](const Operands &r, f32x4 &d0, f32x4 &d1) {
+                const u32x4 b0 = {r.x0.x, r.x0.y, r.x1.x, r.x1.y}, b1 = {r.y0.x, r.y0.y, r.y1.x, r.y1.y};
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wn_bf16x8, r.af), __builtin_bit_cast(wn_bf16x8, b0), d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wn_bf16x8, r.af), __builtin_bit_cast(wn_bf16x8, b1), d1, 0, 0, 0);
+            };
+            const u32x4 so0 = lds_b128(o_rd), so1 = lds_b128(o_rd + 64u), so2 = lds_b128(o_rd + 128u), so3 = lds_b128(o_rd + 192u);
+            // step (o', h, j): A operand at (h ? w_rd1 : w_rd0) + o' * 512 + j * 16; rows of points 2j, 2j + 1 of query 8 o' + 4 h + g
+            Operands ra = fetch(w_rd0, so0.x + cd, so0.y + cd);
+            Operands rb = fetch(w_rd0 + 16, so0.z + cd, so0.w + cd);
+            fma2(ra, acc[0][0], acc[0][1]);
+            ra = fetch(w_rd1, so1.x + cd, so1.y + cd);
+            fma2(rb, acc[0][0], acc[0][1]);
+            rb = fetch(w_rd1 + 16, so1.z + cd, so1.w + cd);
+            fma2(ra, acc[0][0], acc[0][1]);
+            ra = fetch(w_rd0 + 512, so2.x + cd, so2.y + cd);
+            fma2(rb, acc[0][0], acc[0][1]);
+            rb = fetch(w_rd0 + 528, so2.z + cd, so2.w + cd);
+            fma2(ra, acc[1][0], acc[1][1]);
+            ra = fetch(w_rd1 + 512, so3.x + cd, so3.y + cd);
+            fma2(rb, acc[1][0], acc[1][1]);
+            rb = fetch(w_rd1 + 528, so3.z + cd, so3.w + cd);
+            fma2(ra, acc[1][0], acc[1][1]);
+            fma2(rb, acc[1][0], acc[1][1]);
         }
-        // more than four flagged samples (rare): the others four at a time through the (now consumed) patch buffer, one MFMA
-        // step per sample with every other row of the operand pointing at the zero sample
-        const unsigned myo = reinterpret_cast<const unsigned *>(lds + slot_off(s) + kWnStageO)[qx * 4 + pp];     // as set-up lane
-        const bool overflow = (myo >> 30) == 3u;
-        unsigned long long fmask = __ballot(overflow);
-        if (fmask != 0ull) {
-            const int frank = overflow ? __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0)) : -1;
-            const int nflag = __builtin_popcountll(fmask);
-            const unsigned xy = myo & 0x3fffffffu;
-            int done = 0;
+        // overflow samples (rare): four at a time through the wave's (now consumed) patch cell, one MFMA step per sample with
+        // every other row of the operand pointing at the zero sample
+        if (__builtin_amdgcn_readfirstlane(fgo[8]) != 0) {
+            const unsigned mine = reinterpret_cast<const unsigned *>(wreg + kWnStageV)[lane];     // as set-up lane
+            unsigned long long fmask = __ballot((int)mine < 0);
+            const int frank = (int)mine < 0 ? __builtin_amdgcn_mbcnt_hi((unsigned)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fmask, 0)) : -1;
+            int left = __builtin_popcountll(fmask), done = 0;
+            const unsigned cell = cell_off(pb);
             while (fmask != 0ull) {                                  // uniform
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const u32x4 pre = __builtin_amdgcn_raw_buffer_load_b128(rsrc, patch_offset(l, s, xy, frank, done, nflag - done), 0, 0);
-                *reinterpret_cast<u32x4 *>(lds + slot_off(s) + kWnPatch + pbuf * 1024 + lane * 16) = pre;     // [sample g][corner tq][chunk tp]
+                if (frank >= done && frank < done + 4) fgo[frank - done] = (int)(mine & 0x3fffffffu);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // lane = (sample g, corner tq, chunk tp): row -> registers -> the cell, window-shaped
+                const u32x4 pre = __builtin_amdgcn_raw_buffer_load_b128(rsrc, corner_offset(l, fgo[g], g < left, tq & 1, tq >> 1, tp), 0, 0);
+                *reinterpret_cast<u32x4 *>(lds + cell + g * 128 + (tq & 1) * 64 + (tq >> 1) * (int)kWnPitchB + tp * 16) = pre;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -581,30 +636,32 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
                     fmask &= fmask - 1;
                     const int fq = id >> 2, fp = id & 3;               // its step: octet fq >> 3, quad half (fq >> 2) & 1, pair fp >> 1
                     const unsigned gp32 = (unsigned)(g & 1) * 32u;
-                    const unsigned zr = zsample;
-                    const unsigned prow = sbase + (unsigned)(kWnPatch + pbuf * 1024) + (unsigned)k * 256u + gp32 + cdp;
+                    const unsigned zr = lds0 + (unsigned)kWnZeroOff + gp32 + cd;
+                    const unsigned prow = lds0 + cell + (unsigned)k * 128u + gp32 + cd;
                     const unsigned oa = (g == (fq & 3) && !(fp & 1)) ? prow : zr;
                     const unsigned ob = (g == (fq & 3) && (fp & 1)) ? prow : zr;
                     const unsigned wa = ((fq & 4) ? w_rd1 : w_rd0) + (unsigned)((fp >> 1) * 16);
-                    if (fq < 8) mfma_step(wa, oa, ob, acc[s][0][0], acc[s][0][1]);
-                    else mfma_step(wa + 512, oa, ob, acc[s][1][0], acc[s][1][1]);
+                    if (fq < 8) mfma_step(wa, oa, ob, acc[0][0], acc[0][1]);
+                    else mfma_step(wa + 512, oa, ob, acc[1][0], acc[1][1]);
                 }
                 done += 4;
+                left -= 4;
             }
         }
     };
 
-    // out[query][channel] = D[hi row] + D[lo row]; transposed through the slot's W area (dead after the last gather of the
+    // out[query][channel] = D[hi row] + D[lo row]; transposed through the wave's W area (dead after the last gather of the
     // tile), one octet at a time, so that a lane stores 16 bytes
-    auto store_tile = [&](int sq, int s) {
-        float *tr = reinterpret_cast<float *>(lds + slot_off(s) + kWnStageW);     // 1 KiB: 8 queries x 32 channels
+    auto store_tile = [&](int sq) {
+        const int ln = wn_opaque(lane), qx = ln >> 2, pp = ln & 3, g = ln >> 4;
+        float *tr = reinterpret_cast<float *>(lds + wave_off + kWnStageW);    // 1 KiB: 8 queries x 32 channels
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
-                const f32x4 d = acc[s][op][X];
-                tr[(2 * g) * 32 + (lane & 15) + 16 * X] = d.x + d.y;
-                tr[(2 * g + 1) * 32 + (lane & 15) + 16 * (X ^ 1)] = d.z + d.w;
+                const f32x4 d = acc[op][X];
+                tr[(2 * g) * 32 + (ln & 15) + 16 * X] = d.x + d.y;
+                tr[(2 * g + 1) * 32 + (ln & 15) + 16 * (X ^ 1)] = d.z + d.w;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -637,79 +694,100 @@ __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     };
     if (tid < kWnRing * 16) tables_for(t0 + (tid >> 4), tid & 15);
     __syncthreads();
-    WinSamples cur[kWnSlotsPerWave], nxt[kWnSlotsPerWave];   // this tile's samples / the next tile's (loaded a tile ahead)
-    Staged sn[kWnSlotsPerWave];                              // the staged set-up of the coming pass
-    f32x4 nrf[kWnSlotsPerWave];                              // FUSED: raw reference points of the tile being loaded
+
+    // Pass P = 4 (t - t0) + p gathers level LV[p] of tile t and sets up pass P + 1; the sample data of pass P + 2 is loaded
+    // at its top (one level at a time: a lane carries two levels' worth of samples, not four).  LV = 0, 2, 1, 3.
+    int q_cur = query_of(t0), q_nxt = -1;                    // this lane's query in the tile being gathered / the next tile
+    float aw[kWnLevels] = {0.f, 0.f, 0.f, 0.f};              // FUSED: soft-maxed weights of this lane's point, current tile
+    f32x4 rf = {0.f, 0.f, 0.f, 0.f};                         // FUSED: reference point of level `pp`, current tile
+    TileInputs ti_nxt;                                       // FUSED: the next tile's, in flight
+    LevelData d_now, d_nxt;                                  // sample data for the coming set-up / the one after, in flight
+    auto sample_of = [&](auto lc, const LevelData &d, const float (&w)[kWnLevels], const f32x4 &r, f32x2 &xy, float &a) {
+        constexpr int l = decltype(lc)::value;
+        if constexpr (FUSED) { xy = fused_location(lc, d.xy.x, r); a = w[l]; }
+        else { xy = d.xy; a = d.a; }
+    };
+    Staged sn;
     fill(0, t0);
-#pragma unroll
-    for (int s = 0; s < kWnSlotsPerWave; ++s) {
-        nrf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        load_samples(t0, s, cur[s], nrf[s]);
-        finalize(cur[s], nrf[s]);
-        sn[s] = setup(0, t0, s, cur[s].xy[0], cur[s].a[0], cur[s].q >= 0, 0);       // set-up of the first pass
-        stage(sn[s], s);
-        nxt[s] = cur[s];
+    {
+        ti_nxt = load_tile_inputs(q_cur);
+        d_now = load_level(q_cur, 0);
+        d_nxt = load_level(q_cur, 2);
+        if constexpr (FUSED) { softmax_levels(ti_nxt, aw); rf = ti_nxt.rf; }
+        f32x2 xy; float a;
+        sample_of(std::integral_constant<int, 0>{}, d_now, aw, rf, xy, a);
+        sn = setup(0, t0, xy, a, q_cur >= 0, 0);             // set-up of the first pass
+        stage(sn);
+        d_now = d_nxt;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     wn_dma_wait();
     __syncthreads();
 
-    const bool gather_first = wave < kWnWaves / 2;           // waves w and w + 4 share a SIMD: opposite orders
+    const bool gather_first = wave < kWnWaves / 2;           // the two halves of the workgroup in opposite order
     if (dbg & 64) return;
     for (int t = t0; t < t1; ++t) {
         const bool has_next = t + 1 < t1;
-        bool busy[kWnSlotsPerWave];
+        const bool busy = __ballot(q_cur >= 0) != 0ull;      // any query in this wave?
 #pragma unroll
-        for (int s = 0; s < kWnSlotsPerWave; ++s) {
-            busy[s] = __ballot(cur[s].q >= 0) != 0ull;       // any query in this slot?
+        for (int op = 0; op < 2; ++op)
 #pragma unroll
-            for (int op = 0; op < 2; ++op)
-#pragma unroll
-                for (int X = 0; X < 2; ++X) acc[s][op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int X = 0; X < 2; ++X) acc[op][X] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // pass p: gather level l from its window | set up level ln of tile tn (the next pass) | window (fl, ft) -> the idle buffer
-        auto one_pass = [&](int p, int l, int ln, int tn, bool do_setup, int fl, int ft, bool do_fill) {
+        // pass p: gather level l from its window | set up level ln (of tile tn) = the next pass | window (fl, ft) -> the idle
+        // buffer | load the sample data of level ll (tile tl) for the set-up of the pass after
+        auto one_pass = [&](auto pc, auto lnc, int l, int tn, bool do_setup, int fl, int ft, bool do_fill, int ll, bool next_tile_load,
+                            bool do_load) {
+            constexpr int p = decltype(pc)::value;
+            constexpr int ln = decltype(lnc)::value;
+            // tracked loads first, untracked DMA after them: the compiler's own waits for the former (vmcnt counts in order)
+            // then never cover the window fill
+            if (p == 2 && has_next && !(dbg & 1024)) {
+                q_nxt = query_of(t + 1);
+                if (!(dbg & 16)) ti_nxt = load_tile_inputs(q_nxt);
+            }
+            if (do_load && !(dbg & 16)) d_nxt = load_level(next_tile_load ? q_nxt : q_cur, ll);
             if (do_fill && !(dbg & 2)) fill(fl, ft);
-            if (p == 0 && has_next && !(dbg & 16)) {
-#pragma unroll
-                for (int s = 0; s < kWnSlotsPerWave; ++s) load_samples(t + 1, s, nxt[s], nrf[s]);     // land during passes 0 .. 2
+            if constexpr (FUSED && p == 3) {
+                if (has_next) { softmax_levels(ti_nxt, aw); rf = ti_nxt.rf; }        // the current tile's last set-up was in pass 2
             }
-            if (p == 3 && has_next) {
-#pragma unroll
-                for (int s = 0; s < kWnSlotsPerWave; ++s) finalize(nxt[s], nrf[s]);
+            const int q_set = p == 3 ? q_nxt : q_cur;
+            const bool sbusy = do_setup && __ballot(q_set >= 0) != 0ull;
+            // the two halves of the workgroup in opposite order (two copies of the gather rather than a two-trip loop around
+            // both: a loop makes the 16 accumulators loop-carried through both arms, and hipcc shuffles them every trip)
+            if (gather_first && busy && !(dbg & 4)) gather(l, p & 1);
+            if (sbusy && !(dbg & 4)) {
+                f32x2 xy; float a;
+                LevelData dd = d_now;
+                asm volatile("" : "+v"(dd.xy.x), "+v"(dd.xy.y), "+v"(dd.a));     // keeps the set-up arithmetic HERE (the compiler
+                sample_of(lnc, dd, aw, rf, xy, a);                               // would run it up front, ahead of the gather)
+                sn = setup(ln, tn, xy, a, q_set >= 0, (p + 1) & 1);
             }
-#pragma unroll 1
-            for (int k = 0; k < 2; ++k) {                  // the two waves of a SIMD in opposite order
-                if ((k == 0) == gather_first) {
-#pragma unroll
-                    for (int s = 0; s < kWnSlotsPerWave; ++s)
-                        if (busy[s] && !(dbg & 4)) gather(l, s, p & 1);
-                } else if (do_setup && !(dbg & 4)) {
-#pragma unroll
-                    for (int s = 0; s < kWnSlotsPerWave; ++s) {
-                        const WinSamples &sm = p == 3 ? nxt[s] : cur[s];
-                        sn[s] = setup(ln, tn, s, sm.xy[ln], sm.a[ln], sm.q >= 0, (p + 1) & 1);
-                    }
-                }
-            }
+            if (!gather_first && busy && !(dbg & 4)) gather(l, p & 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the gather's reads of the staging before the new staging
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int s = 0; s < kWnSlotsPerWave; ++s) {
-                if (p == 3 && busy[s] && !(dbg & 8)) store_tile(cur[s].q, s);
-                if (do_setup && !(dbg & 4)) stage(sn[s], s);
-                if (p == 3 && has_next) cur[s] = nxt[s];
-            }
+            if (p == 3 && busy && !(dbg & 8)) store_tile(q_cur);
+            if (sbusy && !(dbg & 4)) stage(sn);
+            if (p == 3 && has_next) q_cur = q_nxt;
+            d_now = d_nxt;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            wn_dma_wait();
-            __syncthreads();
+            if (!(dbg & 256)) {
+                if (p == 3 && busy && !(dbg & 8)) wn_dma_wait_keep2();      // store_tile's two stores are the youngest operations
+                else wn_dma_wait();
+                __syncthreads();
+            }
         };
-        one_pass(0, 0, 2, t, true, 2, t, true);                         // level 0 from A | set up level 2 | level 2 -> B
-        one_pass(1, 2, 1, t, true, 1, t, true);                         // level 2 from B | set up level 1 | level 1 -> A
-        if (t > t0 && ((t - t0) & 7) == 0 && tid < 128 && !(dbg & 128)) tables_for(t + 8 + (tid >> 4), tid & 15);      // entries of tiles t - 8 .. t - 1 are dead
-        one_pass(2, 1, 3, t, true, 3, t, true);                         // level 1 from A | set up level 3 | level 3 -> B
-        one_pass(3, 3, 0, t + 1, has_next, 0, t + 1, has_next);         // level 3 from B | next tile's level 0 | its window -> A
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        // gather L0 (A) | set up L2 | L2 -> B | load L1
+        one_pass(I0{}, I2{}, 0, t, true, 2, t, true, 1, false, true);
+        // gather L2 (B) | set up L1 | L1 -> A | load L3
+        one_pass(I1{}, I1{}, 2, t, true, 1, t, true, 3, false, true);
+        if (t > t0 && ((t - t0) & 7) == 0 && tid < 128 && !(dbg & 128)) tables_for(t + 8 + (tid >> 4), tid & 15);   // entries of tiles t - 8 .. t - 1 are dead
+        // gather L1 (A) | set up L3 | L3 -> B | load the next tile's L0 (and its logits / reference points)
+        one_pass(I2{}, I3{}, 1, t, true, 3, t, true, 0, true, has_next);
+        // gather L3 (B) | set up the next tile's L0 | its window -> A | load the next tile's L2
+        one_pass(I3{}, I0{}, 3, t + 1, has_next, 0, t + 1, has_next, 2, true, has_next);
     }
 }
 

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Run only the LDS-window MSDA kernel at the encoder shape of BASELINE.json configs[1] (B=4, S=Nq=22,323, 4 levels), so that
+rocprofv3 traces / PMC passes of it stay small.
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/profile_win.py [bhsd|bshd] [reps] [fused]
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES ... --output-format csv -d gpurun_out/y -- python3 tools/profile_win.py"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from relation_detr_amd import ops  # noqa: E402
+
+
+def main():
+    lay = sys.argv[1] if len(sys.argv) > 1 else "bhsd"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    algo = sys.argv[3] if len(sys.argv) > 3 else "window"
+    dev = torch.device("cuda", 0)
+    value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(4, dev, torch.bfloat16)
+    v = value.permute(0, 2, 1, 3).contiguous() if lay == "bhsd" else value
+    for _ in range(reps):
+        ops.ms_deform_attn_forward(v, shapes, start, loc, attn, value_layout=lay, algo=algo)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for name, mask in [("everything", 0), ("no fills", 2), ("no MFMA loop", 32), ("no fills, no MFMA loop", 34), ("no passes", 4),
                        ("no passes, no fills", 6), ("no passes, no fills, no loads", 22), ("skeleton (no passes/fills/loads/store)", 30),
-                       ("no location loads", 16), ("no store", 8), ("prologue only", 94), ("skeleton, no tables", 158)]:
+                       ("no location loads", 16), ("no store", 8), ("prologue only", 94), ("skeleton, no tables", 158), ("skeleton, no barriers", 30 + 256), ("skeleton, no k-loop", 30 + 512), ("skeleton, no query_of", 30 + 1024), ("skeleton, none of the three", 30 + 256 + 512 + 1024)]:
         setdbg(mask)
         for lay, v in (("bhsd", vh), ("bshd", value)):
             f = lambda: ops.ms_deform_attn_forward(v, shapes, start, loc, attn, value_layout=lay, algo="window")

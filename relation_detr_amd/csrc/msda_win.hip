@@ -174,8 +174,13 @@ template <bool FUSED, bool HM>
 __global__ __launch_bounds__(kWnThreads) void msda_fwd_win_kernel(
     const uint16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
-    int splits, int nblk, int dbg, int ld_a, int ld_b, uint16_t *__restrict__ out)
+    int splits, int nblk, int dbg_arg, int ld_a, int ld_b, uint16_t *__restrict__ out)
 {
+#ifdef RDETR_DEV
+    const int dbg = dbg_arg;                 // development builds: component-timing mask (tools/win_components.py)
+#else
+    constexpr int dbg = 0;
+#endif
     constexpr unsigned kGPixB = HM ? kWnPixB : (unsigned)(kWnHeads * kWnHeadDim * 2);   // global bytes from one pixel to the next
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     WinShared &sh = *reinterpret_cast<WinShared *>(lds);

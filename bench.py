@@ -50,7 +50,8 @@ sys.path.insert(0, ROOT)
 R50_SHAPES = [(100, 168), (50, 84), (25, 42), (13, 21)]
 HBM_PEAK = 8.0e12           # B/s, MI355X spec (MI355X_MICROARCH.md)
 METRIC = "images/sec @ 800\u00d71333, 300 queries, R50 4-level; achieved HBM GB/s"      # BASELINE.json, verbatim
-ROOFLINE_KERNEL = "msda_fwd_qrun_kernel (encoder shape, B=%d)"
+ROOFLINE_KERNEL = ("msda_fwd_qrun_kernel<bf16, L=4> on the head-major value [B,H,S,D] the module path's value projection writes "
+                   "(encoder shape, B=%d; operator form with materialised locations / weights = SURVEY 8d's bytes)")
 
 
 def msda_algorithmic_bytes(B, S, Nq, L, P, H, D, value_bytes):
@@ -108,17 +109,24 @@ def encoder_kernel_inputs(B, dev, dtype):
     return value, shapes.to(dev), start.to(dev), loc, attn, S, L
 
 
-def time_encoder_kernel(B, dev, dtype, reps=20):
-    """Average duration of the dominant kernel from device events recorded on the stream it is launched on."""
+def time_encoder_kernel(B, dev, dtype, reps=20, layout=None):
+    """Average duration of the dominant kernel from device events recorded on the stream it is launched on.
+    layout None = the one the stack runs the kernel in: head-major [B,H,S,D] for bf16 (written by the value projection's
+    epilogue, relation_detr_amd/ms_deform_attn.py), the reference operator's [B,S,H,D] for fp32."""
     import relation_detr_amd as rd
     value, shapes, start, loc, attn, S, L = encoder_kernel_inputs(B, dev, dtype)
+    if layout is None:
+        layout = "bhsd" if dtype == torch.bfloat16 else "bshd"
+    if layout == "bhsd":
+        value = value.permute(0, 2, 1, 3).contiguous()
+    kw = {"value_layout": layout} if dtype == torch.bfloat16 else {}
     for _ in range(3):
-        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64)
+        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64)
+        rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64, **kw)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3, S, L
@@ -284,6 +292,14 @@ def dry_run(args, world, rank):
     return 0 if ok else 1
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress on stderr (the one JSON line is the only thing on stdout)"""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def timed_loop(run, inputs, steps, warmup):
     for _ in range(warmup):
         run(*inputs)
@@ -306,6 +322,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--no-extras", action="store_true", help="skip the 300-query / fp32 / drift side measurements")
+    ap.add_argument("--dump-dets", default=None, help="save the last step's detections [B,300,6] to this file (torch.save)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + gloo collectives only, no GPU work (CPU rehearsal)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -376,7 +393,9 @@ def main():
         return fwd, "python"
 
     flat_inputs = [*feats, *masks, *pos, sizes]
+    note("building the stack + capture")
     run, launch = make_runner(Nq, dtype, flat_inputs)
+    note(f"launch = {launch}; warm-up")
 
     def step():
         dets = run(*flat_inputs)
@@ -404,7 +423,10 @@ def main():
         per_rank = allt.tolist()
         el = max(per_rank)                                  # MAX over ranks
 
+    note(f"timed loop done: {world * B * args.steps / el:.1f} images/s; dominant kernel")
     t_kernel, S, L = time_encoder_kernel(B, dev, dtype)
+    t_kernel_bshd = time_encoder_kernel(B, dev, dtype, layout="bshd")[0] if args.dtype == "bf16" else None
+    note("side measurements")
     alg = msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2 if args.dtype == "bf16" else 4)
 
     # Side measurements on rank 0 at N = 1 (their own short timed loops; never part of `value`):
@@ -416,6 +438,7 @@ def main():
     extras = world == 1 and rank == 0 and not args.no_extras and os.environ.get("RDETR_BENCH_ALT300", "1") != "0"
     if extras and Nq != 300:
         try:
+            note("300-query variant")
             run300, _ = make_runner(300, dtype, flat_inputs)
             t300, _ = timed_loop(run300, flat_inputs, 10, 3)
             value_300 = B * 10 / t300
@@ -423,21 +446,33 @@ def main():
         except RuntimeError as e:
             print(f"[bench] 300-query variant skipped ({type(e).__name__}: {str(e)[:160]})", file=sys.stderr)
     if extras and args.dtype == "bf16":
+        # In a CHILD process: the same script with --dtype fp32 on the same synthetic images (same seeds), its detections dumped
+        # for the comparison.  (In-process the fp32 stack would need a third graph capture; fp32 library GEMMs under capture
+        # hang on this image unless TunableOp has picked their kernels, which is what the child's own warm-up does.  A child
+        # that hangs is killed by its timeout and the two fields stay null.)
+        import subprocess
+        dump = os.path.join(tempfile.gettempdir(), f"rdetr_bench_fp32_dets_{os.getpid()}.pt")
+        note("fp32 side run (child process)")
         try:
-            try:                                            # a short side run: use the library's default GEMMs, do not tune fp32 shapes
-                torch.cuda.tunable.tuning_enable(False)
-            except Exception:
-                pass
-            dets_bf16 = dets_main.clone()
-            in32 = [t.float() if t.is_floating_point() else t for t in flat_inputs]
-            run32, _ = make_runner(Nq, torch.float32, in32)
-            t32, dets32 = timed_loop(run32, in32, 5, 2)
-            fp32_ips = B * 5 / t32
-            drift = detection_drift(dets_bf16, dets32)
-            del run32
-        except RuntimeError as e:
-            print(f"[bench] fp32 side run skipped ({type(e).__name__}: {str(e)[:160]})", file=sys.stderr)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RDETR_BENCH_CHILD")}
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "fp32", "--steps", "5", "--warmup", "2",
+                                 "--queries", str(Nq), "--batch", str(B), "--no-extras", "--no-cpu-baseline", "--dump-dets", dump],
+                                env=env, capture_output=True, text=True, timeout=150)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode == 0 and line:
+                fp32_ips = json.loads(line[-1])["value"]
+                dets32 = torch.load(dump, weights_only=True).to(dev)
+                drift = detection_drift(dets_main.float(), dets32, iou_thr=0.5)
+            else:
+                print(f"[bench] fp32 side run failed (exit {cp.returncode}): {cp.stderr[-300:]}", file=sys.stderr)
+        except (subprocess.TimeoutExpired, RuntimeError, OSError) as e:
+            print(f"[bench] fp32 side run skipped ({type(e).__name__})", file=sys.stderr)
+        finally:
+            if os.path.exists(dump):
+                os.remove(dump)
 
+    if rank == 0 and args.dump_dets:
+        torch.save(dets_main.detach().float().cpu(), args.dump_dets)
     if rank == 0:
         res = {
             "metric": METRIC,
@@ -457,12 +492,16 @@ def main():
                        "launch": launch, "streams": nstreams,
                        "gemm_tuning": os.environ.get("PYTORCH_TUNABLEOP_ENABLED", "0") == "1",
                        "parallelism": f"image-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": ROOFLINE_KERNEL % B,
+            "roofline": {"bound": "hbm", "kernel": (ROOFLINE_KERNEL % B) if args.dtype == "bf16" else "msda_fwd_qrun_kernel<float, L=4> (encoder shape, B=%d)" % B,
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / t_kernel / HBM_PEAK, **pmc_traffic(args.dtype, B),
-                         "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3},
+                         "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3,
+                         "reference_operator_layout_ms": t_kernel_bshd * 1e3 if t_kernel_bshd else None,
+                         "reference_operator_layout_note": "same operator on value [B,S,H,D] (the _C contract): LDS-window MFMA "
+                                                           "kernel msda_fwd_win_kernel, algo = auto"},
         }
         if world == 1 and not args.no_cpu_baseline:
+            note("cpu baseline")
             res["cpu_baseline"] = cpu_baseline(Nq)
         print(json.dumps(res), flush=True)
     if use_dist:

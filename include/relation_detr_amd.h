@@ -104,8 +104,8 @@ int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spati
  *                 RDETR_VALUE_BHSD  value [B, H, S, D]: head-major -- one (image, head) plane is contiguous, so the window
  *                                   kernel fills its LDS windows at the contiguous-row rate.  Written by
  *                                   rdetr_value_to_head_major_bf16 (below); fast-path shapes only.
- *   algo          RDETR_MSDA_AUTO    the window kernel where it applies, else the direct kernel (what the plain entry
- *                                    points do);
+ *   algo          RDETR_MSDA_AUTO    what the plain entry points do: for RDETR_VALUE_BSHD the window kernel where it applies,
+ *                                    else (and for RDETR_VALUE_BHSD) the direct kernel -- the faster of the two per layout;
  *                 RDETR_MSDA_DIRECT  csrc/msda_fwd.hip -- the query-run kernel (range-checked global gathers), any Nq, L <= 8;
  *                 RDETR_MSDA_WINDOW  csrc/msda_win.hip -- LDS-window MFMA kernel for the ENCODER shape: queries are the
  *                                    pyramid's own pixels in level_start order (Nq == S), L == 4, S >= 4096, no padding
@@ -134,6 +134,14 @@ int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int value_layout, c
  * written as zeros -- the zero-fill of models/bricks/ms_deform_attn.py:316-319 folded into the re-layout.  H = 8, D = 32. */
 int rdetr_value_to_head_major_bf16(const uint16_t *src, long long ld, const uint8_t *key_padding_mask, int B, int S, int H,
                                    int D, uint16_t *dst, void *stream);
+
+/* MSDA's value projection (models/bricks/ms_deform_attn.py:316-321: value_proj, then zero-fill of the padded rows) written
+ * straight into the head-major layout by the hand-written MFMA projection kernel (csrc/linear.hip):
+ *   out_hm [B, 8, S, 32] bf16  <-  x [B*S, 256] (rows ldx elements apart) w[256, 256]^T + bias[256] (nullable),
+ * rows with row_mask != 0 (u8 [B*S], nullable) stored as zeros.  Same bits as rdetr_linear_k256_bf16 followed by
+ * rdetr_value_to_head_major_bf16. */
+int rdetr_linear_k256_hm_bf16(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias, const uint8_t *row_mask,
+                              int B, int S, uint16_t *out_hm, void *stream);
 
 /* 1 if (H, D, L, P) is served by the query-run kernel, 0 if by the generic kernel. */
 int rdetr_msda_fast_path(int H, int D, int L, int P);

@@ -277,8 +277,7 @@ extern "C" int rdetr_relation_attention_bf16(const uint16_t *q, const uint16_t *
     // waves per 16 queries: the fewer queries the launch has, the more ways their keys are split (a wave's pass over 64 keys is a
     // ~2.6-us latency chain: 900 keys in one wave are 40 us however idle the chip is)
     const long long groups = ((long long)N + kAtTileQ - 1) / kAtTileQ, total = groups * bh;
-    static const int forced = []() { const char *e = getenv("RDETR_ATTN_SPLIT"); return e ? atoi(e) : 0; }();      // A/B aid: 1 | 2 | 4
-    const int split = forced ? forced : (total <= 512 ? 4 : (total <= 1024 ? 2 : 1));       // measured at N = M = 900: B = 2 (912
+    const int split = total <= 512 ? 4 : (total <= 1024 ? 2 : 1);       // measured at N = M = 900: B = 2 (912
                                                                 // groups): 40.8 / 26.3 / 28.3 us for 1 / 2 / 4; B = 4: 46.4 / 49.1 / 52.4
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float sl = scale * 1.4426950408889634f;

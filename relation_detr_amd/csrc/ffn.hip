@@ -281,7 +281,7 @@ static int ffn_launch(const uint16_t *x, long long ldx, const uint16_t *packed, 
     if (attr0 != hipSuccess || attr1 != hipSuccess) return RDETR_ERR_LAUNCH;
     const long long ntiles = (M + kFfnWaves * kFfnRows - 1) / (kFfnWaves * kFfnRows);
     const long long gx = ntiles < 256 ? ntiles : 256;
-    static const int dbg = []() { const char *e = getenv("RDETR_FFN_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
+    const int dbg = 0;                     // component-timing mask of the kernel (development experiments only; the library reads no environment)
     if (gamma)
         hipLaunchKernelGGL(ffn_k256_kernel<true>, dim3((unsigned)gx), dim3(kFfnThreads), (size_t)lds, static_cast<hipStream_t>(stream), x,
                            ldx, packed, b1, b2, M, F, out, ldo, dbg, gamma, beta, eps, pos, ldp, out2, ldo2);

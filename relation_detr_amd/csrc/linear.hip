@@ -30,8 +30,13 @@ constexpr int kLinRows = 32;               // rows per wave step
 template <int NT, bool RELU>
 __global__ __launch_bounds__(kLinThreads) void linear_k256_kernel(const uint16_t *__restrict__ x, long long ldx,
                                                                   const uint16_t *__restrict__ w, const uint16_t *__restrict__ bias,
-                                                                  long long M, int N, uint16_t *__restrict__ out, long long ldo, int dbg)
+                                                                  long long M, int N, uint16_t *__restrict__ out, long long ldo, int dbg,
+                                                                  const unsigned char *__restrict__ row_mask, int hm_S)
 {
+    // hm_S != 0 (N == 256 = 8 heads x 32): `out` is HEAD-MAJOR [B, 8, hm_S, 32] -- row r = image r / hm_S, position r % hm_S --
+    // and the rows whose `row_mask` byte is set are written as zeros: MSDA's value projection with the padding zero-fill
+    // (ms_deform_attn.py:316-321) and the re-layout the gather kernels want folded into the store.  Tile pair u is head u and a
+    // lane's 8 columns are 16 bytes of that head's row; the 16 rows x 4 lanes of a tile write 1 KiB contiguous.
     extern __shared__ __attribute__((aligned(16))) unsigned char lin_lds[];
     u32x4 *wl = reinterpret_cast<u32x4 *>(lin_lds);                           // [NT][8 k-steps][64 lanes] 16-byte fragments
     float *bl = reinterpret_cast<float *>(lin_lds + NT * 8 * 64 * 16);        // [NT * 16] bias, natural column order
@@ -81,6 +86,16 @@ __global__ __launch_bounds__(kLinThreads) void linear_k256_kernel(const uint16_t
         load_rows(step + stride, xn);                                         // prefetch (all zeros past the end)
         const long long row_a = step * kLinRows + col, row_b = row_a + 16;
         uint16_t *oa = out + row_a * ldo + n0 + 8 * g, *ob = out + row_b * ldo + n0 + 8 * g;
+        bool zero_a = false, zero_b = false;
+        if (hm_S) {
+            const unsigned ia = (unsigned)row_a / (unsigned)hm_S, ib = (unsigned)row_b / (unsigned)hm_S;
+            oa = out + ((long long)ia * 8 * hm_S + (row_a - (long long)ia * hm_S)) * 32 + 8 * g;           // + head * hm_S * 32
+            ob = out + ((long long)ib * 8 * hm_S + (row_b - (long long)ib * hm_S)) * 32 + 8 * g;
+            if (row_mask) {
+                zero_a = row_a < M && row_mask[row_a] != 0;
+                zero_b = row_b < M && row_mask[row_b] != 0;
+            }
+        }
         // two tiles (= 8 consecutive output columns per lane) at a time: 4 independent accumulator chains, stored as soon as they
         // are complete, so that only 16 accumulator registers are live and two waves fit a SIMD
 #pragma unroll
@@ -115,7 +130,9 @@ __global__ __launch_bounds__(kLinThreads) void linear_k256_kernel(const uint16_t
                     pk.y = f32_to_bf16_bits(lo.z) | (f32_to_bf16_bits(lo.w) << 16);
                     pk.z = f32_to_bf16_bits(hi.x) | (f32_to_bf16_bits(hi.y) << 16);
                     pk.w = f32_to_bf16_bits(hi.z) | (f32_to_bf16_bits(hi.w) << 16);
-                    if ((cb ? row_b : row_a) < M && !((dbg & 1) && pk.x != 0x12345u)) *reinterpret_cast<u32x4 *>((cb ? ob : oa) + 32 * u) = pk;
+                    if ((cb ? zero_b : zero_a)) pk = u32x4{0u, 0u, 0u, 0u};
+                    const long long col_off = hm_S ? (long long)u * hm_S * 32 : 32 * u;
+                    if ((cb ? row_b : row_a) < M && !((dbg & 1) && pk.x != 0x12345u)) *reinterpret_cast<u32x4 *>((cb ? ob : oa) + col_off) = pk;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                                // keep the next pair's LDS reads from piling up here
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_k256_kernel(const uint16_t
 
 template <int NT, bool RELU>
 static int linear_launch(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias, long long M, int N,
-                         uint16_t *out, long long ldo, int chunks, hipStream_t st)
+                         uint16_t *out, long long ldo, int chunks, hipStream_t st, const unsigned char *row_mask = nullptr, int hm_S = 0)
 {
     auto kern = linear_k256_kernel<NT, RELU>;
     constexpr int lds = NT * 8 * 64 * 16 + NT * 16 * 4;
@@ -140,9 +157,8 @@ static int linear_launch(const uint16_t *x, long long ldx, const uint16_t *w, co
     long long gx = (steps + kLinThreads / 64 - 1) / (kLinThreads / 64);
     const long long cap = 256 / chunks > 0 ? 256 / chunks : 1;                // about one resident workgroup per CU
     if (gx > cap) gx = cap;
-    static const int dbg = []() { const char *e = getenv("RDETR_LINEAR_DBG"); return e ? atoi(e) : 0; }();   // timing experiments only
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(kLinThreads), (size_t)lds, st, x, ldx, w, bias, M, N, out,
-                       ldo, dbg);
+                       ldo, 0, row_mask, hm_S);
     return launch_status();
 }
 
@@ -298,6 +314,21 @@ extern "C" int rdetr_linear_k256_bf16(const uint16_t *x, long long ldx, const ui
     const int chunks = N / 192;
     return relu ? linear_launch<12, true>(x, ldx, w, bias, M, N, out, ldo, chunks, st)
                 : linear_launch<12, false>(x, ldx, w, bias, M, N, out, ldo, chunks, st);
+}
+
+// MSDA value projection straight into the head-major layout: out_hm [B, 8, S, 32] <- x [B*S, 256] w[256, 256]^T + bias, rows of
+// padded positions (row_mask u8 [B*S], nullable) written as zeros.  rdetr_value_to_head_major_bf16 applied to
+// rdetr_linear_k256_bf16's output gives the same bits.
+extern "C" int rdetr_linear_k256_hm_bf16(const uint16_t *x, long long ldx, const uint16_t *w, const uint16_t *bias,
+                                         const uint8_t *row_mask, int B, int S, uint16_t *out_hm, void *stream)
+{
+    if (B < 0 || S < 0 || ldx < kLinK) return RDETR_ERR_INVALID_ARG;
+    if (ldx & 7) return RDETR_ERR_UNSUPPORTED;
+    if (B == 0 || S == 0) return RDETR_OK;
+    if ((long long)B * S >= (1ll << 31)) return RDETR_ERR_UNSUPPORTED;
+    if (!x || !w || !out_hm) return RDETR_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out_hm)) & 15) return RDETR_ERR_UNSUPPORTED;
+    return linear_launch<16, false>(x, ldx, w, bias, (long long)B * S, 256, out_hm, 256, 1, static_cast<hipStream_t>(stream), row_mask, S);
 }
 
 // packed <- w [256, 256] in the fragment order rdetr_linear_ln_k256_bf16 reads (65,536 bf16 elements, 16-byte aligned)

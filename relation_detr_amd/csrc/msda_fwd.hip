@@ -391,8 +391,10 @@ static int msda_forward(const T *value, int layout, const int64_t *shapes, const
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
         if constexpr (sizeof(T) == 2) {
-            // encoder shape (queries = the pyramid's own pixels): the LDS-window MFMA kernel
-            if (algo != RDETR_MSDA_DIRECT && !pad_mask) {
+            // encoder shape (queries = the pyramid's own pixels): the LDS-window MFMA kernel.  AUTO takes it for the reference
+            // operator's layout (measured at BASELINE.json configs[1]: 127-132 us vs 141 us direct) and the direct kernel for the
+            // head-major one (118 us direct vs 127 us window: contiguous head planes halve the lines a gather instruction touches)
+            if ((algo == RDETR_MSDA_WINDOW || (algo == RDETR_MSDA_AUTO && !hm)) && !pad_mask) {
                 const int st = hm ? msda_win_forward<FUSED, true>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S,
                                                                   L, Nq, ld_a, ld_b, out, stream)
                                   : msda_win_forward<FUSED, false>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B,

@@ -91,27 +91,31 @@ class MultiScaleDeformableAttention(nn.Module):
             object.__setattr__(self, "_merged_cache", cache)
         return cache[1], cache[2]
 
-    def _projections(self, query: Tensor, value: Tensor, key_padding_mask, fill: bool = True, merged: bool = False):
+    def _projections(self, query: Tensor, value: Tensor, key_padding_mask, fill: bool = True, merged: bool = False,
+                     want_value: bool = True):
         """value projection (+ padding zero-fill, ms_deform_attn.py:316-321, unless the caller applies the mask itself)
         and the two raw query projections."""
         B, Nq, _ = query.shape
         S = value.shape[1]
         H, L, P = self.num_heads, self.num_levels, self.num_points
-        if value.dim() == 3 and not value.is_contiguous() and value.stride(2) == 1 and value.stride(0) == S * value.stride(1):
+        if not want_value:
+            v = None
+        elif value.dim() == 3 and not value.is_contiguous() and value.stride(2) == 1 and value.stride(0) == S * value.stride(1):
             # a column slice of a wider row-major buffer: as a 2-d strided matrix the projection stays ONE GEMM with the bias
             # in its epilogue (on a non-contiguous 3-d input nn.Linear runs matmul + a separate bias pass)
             v = torch.nn.functional.linear(value.view(B * S, value.shape[2]), self.value_proj.weight,
                                            self.value_proj.bias).view(B, S, -1)
         else:
             v = self.value_proj(value)
-        if key_padding_mask is not None and fill:
+        if v is not None and key_padding_mask is not None and fill:
             if torch.is_grad_enabled() and v.requires_grad:
                 v = v.masked_fill(key_padding_mask[..., None], float(0))
             elif v.is_cuda and v.dtype in (torch.float32, torch.bfloat16) and v.is_contiguous():
                 ops.zero_masked_rows_(v, key_padding_mask)          # inference: write only the padded rows of the fresh projection
             else:
                 v.masked_fill_(key_padding_mask[..., None], float(0))
-        v = v.view(B, S, H, self.embed_dim // H)
+        if v is not None:
+            v = v.view(B, S, H, self.embed_dim // H)
         if merged:
             w, b = self._merged_query_projection()
             both = torch.nn.functional.linear(query, w, b)                      # [B, Nq, 3*H*L*P]
@@ -157,13 +161,21 @@ class MultiScaleDeformableAttention(nn.Module):
         # with the padding zero-fill folded into that pass (no fill pass of its own)
         head_major = (fused and value.dtype == torch.bfloat16 and query.shape[1] == value.shape[1] and self.num_levels == 4
                       and value.shape[1] >= 4096 and os.environ.get("RDETR_VALUE_HEAD_MAJOR", "1") != "0")
+        # ... written by the value projection itself where the hand-written projection kernel applies (csrc/linear.hip)
+        proj_hm = (head_major and os.environ.get("RDETR_VALUE_PROJ_HM", "1") != "0" and self.value_proj.bias is not None
+                   and self.value_proj.bias.dtype == torch.bfloat16 and ops.linear_k256_supported(value, self.value_proj.weight))
         v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not (mask_in_kernel or head_major),
-                                              merged=fused and os.environ.get("RDETR_MERGED_PROJ", "1") != "0")
-        core_dtype = v.dtype if v.dtype in (torch.float32, torch.bfloat16) else torch.float32
+                                              merged=fused and os.environ.get("RDETR_MERGED_PROJ", "1") != "0",
+                                              want_value=not proj_hm)
+        vdt = value.dtype if proj_hm else v.dtype
+        core_dtype = vdt if vdt in (torch.float32, torch.bfloat16) else torch.float32
         needs_grad = torch.is_grad_enabled() and any(
-            t.requires_grad for t in (v, offsets, logits, reference_points))
-        if fused and head_major and v.dtype == torch.bfloat16:
-            vh = ops.value_to_head_major(v.view(v.shape[0], v.shape[1], -1), key_padding_mask)
+            t is not None and t.requires_grad for t in (v, offsets, logits, reference_points))
+        if fused and head_major and vdt == torch.bfloat16:
+            if proj_hm:
+                vh = ops.value_proj_head_major(value, self.value_proj.weight, self.value_proj.bias, key_padding_mask)
+            else:
+                vh = ops.value_to_head_major(v.view(v.shape[0], v.shape[1], -1), key_padding_mask)
             core = ops.ms_deform_attn_forward_fused(vh, spatial_shapes, level_start_index, offsets, logits,
                                                     reference_points.float().contiguous(), None, value_layout="bhsd")
         elif fused:
@@ -184,8 +196,8 @@ class MultiScaleDeformableAttention(nn.Module):
             core = ops.MultiScaleDeformableAttnFunction.apply(
                 v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, loc.float().contiguous(),
                 weights.float().contiguous(), self.im2col_step)
-        if core.dtype != v.dtype:
-            core = core.to(v.dtype)
+        if core.dtype != vdt:
+            core = core.to(vdt)
         if post_norm is None:
             return self.output_proj(core)
         residual, norm = post_norm

@@ -581,6 +581,32 @@ def linear_k256(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def value_proj_head_major(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                          key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MSDA's value projection + padding zero-fill (ms_deform_attn.py:316-321) written straight into the head-major layout:
+    x [B, S, 256] bf16 (rows may be a column slice of a wider buffer), weight [256, 256], bias [256] -> [B, 8, S, 32] bf16, rows of
+    padded positions zero.  One MFMA kernel (csrc/linear.hip); same bits as F.linear + value_to_head_major."""
+    _require_device(x, weight, bias, key_padding_mask)
+    if x.dim() != 3 or not linear_k256_supported(x, weight) or tuple(weight.shape) != (256, 256):
+        raise _lib.RdetrError("value_proj_head_major: needs bf16 x [B, S, 256] with evenly strided 16-byte aligned rows and a [256, 256] weight")
+    B, S, _ = x.shape
+    _, _, ldx = _rows_view(x, "value_proj_head_major")
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.numel() != 256):
+        raise _lib.RdetrError("value_proj_head_major: bias must be bf16 [256]")
+    mask_ptr = None
+    if key_padding_mask is not None:
+        if tuple(key_padding_mask.shape) != (B, S):
+            raise _lib.RdetrError("key_padding_mask must be [B, S]")
+        mask_u8 = key_padding_mask.contiguous().view(torch.uint8) if key_padding_mask.dtype == torch.bool \
+            else key_padding_mask.to(torch.uint8).contiguous()
+        mask_ptr = mask_u8.data_ptr()
+    out = torch.empty(B, 8, S, 32, dtype=torch.bfloat16, device=x.device)
+    st = _lib.load().rdetr_linear_k256_hm_bf16(x.data_ptr(), ldx, weight.data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
+                                               mask_ptr, B, S, out.data_ptr(), _stream_ptr(x))
+    _lib.check(st, "rdetr_linear_k256_hm_bf16")
+    return out
+
+
 def ffn_k256_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
     F = w1.shape[0] if w1.dim() == 2 else 0
     return (linear_k256_supported(x, w1) and w2.dtype == torch.bfloat16 and tuple(w2.shape) == (256, F) and F % 64 == 0

@@ -124,18 +124,23 @@ def test_bf16_two_group_replay_vs_fp32_full_size(bench):
     assert m32.shape == m16.shape and m32.shape[0] == B
     rel = ((m16 - m32).norm() / m32.norm()).item()
     assert rel < 2.0 ** -5, f"encoder memory bf16 vs fp32: relative L2 {rel:.4f}"
-    for h in list(net16.encoder._forward_hooks):
-        del net16.encoder._forward_hooks[h]
+    mem["bf16"].clear()                                  # the hook now fires under capture: its clones live in the graph's pool
     run = GraphedCall(ImageGroups(make(net16), 2, device=DEV), in16)
     det16 = run(*in16).clone()
     torch.cuda.synchronize()
-    # replay vs eager: the same kernels on the same inputs -- but the two-stage torch.topk runs over bf16 scores with many EXACT
-    # ties at this size, and its order among equal scores is not reproducible from call to call; everything downstream of a
-    # swapped tie differs.  (tests/test_gpu_glue.py::test_graph_replay_matches_eager holds replay == eager bit for bit where
-    # there are no ties.)
+    # replay vs eager: the same kernels of this library on the same inputs, but (a) the library GEMMs the heuristics pick under
+    # capture are not always the ones picked eagerly at these shapes (the encoder memory of the two runs differs by a few bf16
+    # ulps after six layers), and (b) the two-stage torch.topk runs over bf16 scores with many EXACT ties, whose order among
+    # equal scores is not reproducible from call to call; one swapped tie changes an image's query set and with it all of
+    # that image's detections (observed: 0, 1 or 2 of the 4 images differ between two runs).
+    # tests/test_gpu_glue.py::test_graph_replay_matches_eager holds replay == eager bit for bit, end to end, at a size where
+    # neither happens.
+    m16_replay = torch.cat(mem["bf16"][-2:], 0)
+    rel_replay = ((m16_replay - m16).norm() / m16.norm()).item()
+    assert rel_replay < 2.0 ** -7, f"encoder memory replay vs eager: relative L2 {rel_replay:.5f}"
     same = bench.detection_drift(det16, eager16, iou_thr=0.9)
     print("replay vs eager:", same)
-    assert same["matched_frac"] >= 0.9, same
+    assert same["matched_frac"] >= 0.45, same
     d = bench.detection_drift(det16, det32, iou_thr=0.5)
     print("bf16 vs fp32 detections:", d, "encoder memory rel L2:", rel)
     assert torch.isfinite(det16).all() and det16.shape == (B, 300, 6)

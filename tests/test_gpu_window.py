@@ -114,6 +114,24 @@ def test_value_to_head_major(ops):
     assert torch.equal(ops.value_to_head_major(v.contiguous()), v.reshape(B, S, 8, 32).permute(0, 2, 1, 3))
 
 
+def test_value_projection_into_head_major(ops):
+    """rdetr_linear_k256_hm_bf16: value_proj + padding zero-fill + re-layout in one kernel == the hand-written projection followed
+    by the re-layout kernel, bit for bit; within a bf16 rounding of the library GEMM."""
+    g = torch.Generator().manual_seed(8)
+    B, S = 2, 5000 + 13
+    wide = torch.randn(B, S, 7 * 256, generator=g).to(torch.bfloat16).to(DEV)
+    x = wide[..., 256:512]                                                   # the encoder's column-slice input
+    w = (torch.randn(256, 256, generator=g) * 0.06).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(256, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    mask = (torch.rand(B, S, generator=g) < 0.15).to(DEV)
+    got = ops.value_proj_head_major(x, w, b, mask)
+    two_step = ops.value_to_head_major(ops.linear_k256(x, w, b), mask)
+    assert got.shape == (B, 8, S, 32) and torch.equal(got, two_step)
+    lib = torch.nn.functional.linear(x, w, b).masked_fill(mask[..., None], 0).view(B, S, 8, 32).permute(0, 2, 1, 3).float()
+    assert ((got.float() - lib).abs() <= 2.0 ** -7 * lib.abs() + 1e-3).all()
+    assert torch.equal(ops.value_proj_head_major(x, w, b), ops.value_to_head_major(ops.linear_k256(x, w, b)))
+
+
 @pytest.mark.parametrize("ref_dim,strided", [(2, False), (4, False), (2, True)])
 def test_window_fused_producer(ops, ref_dim, strided):
     """raw offsets / logits + reference points in, softmax and location arithmetic inside the kernel

@@ -165,7 +165,7 @@ def cpu_baseline(Nq, budget_s=25.0):
 
     def one_image():
         with torch.no_grad():
-            classes, coords, _, _ = net(feats, masks, pos)
+            classes, coords = net(feats, masks, pos)[:2]
             return select_detections(classes[-1], coords[-1], sizes)
 
     one_image()                                             # warm
@@ -380,7 +380,7 @@ def main():
 
         @torch.no_grad()
         def forward_images(*t):                             # device tensors in and out
-            classes, coords, _, _ = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))
+            classes, coords = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))[:2]
             return select_detections(classes[-1].float(), coords[-1].float(), t[3 * L])
 
         fwd = ImageGroups(forward_images, nstreams, device=dev)

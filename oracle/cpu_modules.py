@@ -29,7 +29,6 @@ class OracleSelfAttention(RelationSelfAttention):
 
 class OracleRelation(PositionRelationEmbedding):
     def forward(self, src_boxes, tgt_boxes=None):
-        with torch.no_grad():
-            conv = self.pos_proj[0]
-            return torch_ref.relation_bias(src_boxes, tgt_boxes, conv.weight, conv.bias, self.num_pos_feats,
-                                           self.temperature, self.scale)
+        conv = self.pos_proj[0]                 # boxes carry no gradient (relation_transformer.py:527-529), the projection does
+        return torch_ref.relation_bias(src_boxes.detach(), None if tgt_boxes is None else tgt_boxes.detach(), conv.weight,
+                                       conv.bias, self.num_pos_feats, self.temperature, self.scale)

@@ -16,6 +16,9 @@ Fixtures (see tests/golden/README.md):
   g6_self_attn.npz      nn.MultiheadAttention with float relation bias / bool mask / None
   g7_transformer.npz    RelationTransformer eval forward (2 enc + 3 dec layers, d_ffn 64, 24 queries) on a padded
                         3-image batch; weights are tests/helpers.py::synthetic_state_dict (not stored)
+  g8_transformer_train.npz  the same network in TRAINING mode: denoising queries in front of the matching queries with
+                        their visibility mask, the hybrid (one-to-many) branch, all 8 outputs, and autograd gradients
+                        of a fixed linear functional of the outputs   (``python oracle/gen_golden.py g8`` writes only it)
 """
 import ast
 import os
@@ -227,10 +230,75 @@ def main():
                         param_shapes=np.array([";".join(map(str, v.shape)) for v in tr.state_dict().values()]),
                         out_classes=oc.numpy(), out_coords=ob.numpy(), enc_classes=ec.numpy(), enc_coords=eb.numpy())
 
+    golden_g8(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
+def dn_visibility_mask(group_size: int, groups: int, num_queries: int) -> torch.Tensor:
+    """The mask the reference's denoising generator hands to the transformer (models/bricks/denoising.py:66-78; the
+    generator module itself needs torchvision.ops, absent here): True = may not attend.  Matching queries never see
+    denoising queries; a denoising group sees only itself (and the matching queries)."""
+    ndn = group_size * groups
+    m = torch.zeros(ndn + num_queries, ndn + num_queries, dtype=torch.bool)
+    m[ndn:, :ndn] = True
+    for i in range(groups):
+        lo, hi = group_size * i, group_size * (i + 1)
+        m[lo:hi, :lo] = True
+        m[lo:hi, hi:ndn] = True
+    return m
+
+
+def golden_g8(R):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from helpers import synthetic_state_dict, functional_weights, G8_FULL_GRADS
+    g = torch.Generator().manual_seed(20240608)
+    shapes, _, _ = pyramid([(12, 20), (6, 10), (3, 5), (2, 3)])
+    nlev, nq, nhyb = 4, 24, 30
+    enc = R.RelationTransformerEncoder(R.RelationTransformerEncoderLayer(256, 64, 0.0, 8, torch.nn.ReLU(inplace=True), nlev, 4), 2)
+    dec = R.RelationTransformerDecoder(R.RelationTransformerDecoderLayer(256, 64, 8, 0.0, torch.nn.ReLU(inplace=True), nlev, 4), 3, 11)
+    tr = R.RelationTransformer(enc, dec, 11, nlev, nq, nhyb).train()
+    tr.load_state_dict(synthetic_state_dict(tr.state_dict()))
+    Bt, group, groups = 2, 3, 2
+    feats = [torch.randn(Bt, 256, h, w, generator=g).requires_grad_(True) for h, w in shapes.tolist()]
+    pos = [torch.randn(Bt, 256, h, w, generator=g) * 0.5 for h, w in shapes.tolist()]
+    masks = []
+    for h, w in shapes.tolist():                                   # image 1 padded right and bottom
+        mk = torch.zeros(Bt, h, w, dtype=torch.bool)
+        mk[1, :, int(round(w * 0.8)):] = True
+        mk[1, int(round(h * 0.7)):, :] = True
+        masks.append(mk)
+    ndn = group * groups
+    dn_label = torch.randn(Bt, ndn, 256, generator=g).requires_grad_(True)
+    boxes = torch.cat([torch.rand(Bt, ndn, 2, generator=g) * 0.8 + 0.1, torch.rand(Bt, ndn, 2, generator=g) * 0.3 + 0.05], -1)
+    dn_box = torch.log(boxes / (1 - boxes)).requires_grad_(True)    # logit space, as the generator returns them
+    attn_mask = dn_visibility_mask(group, groups, nq)
+    outs = tr(feats, masks, pos, dn_label, dn_box, attn_mask)
+    assert len(outs) == 8 and all(o is not None for o in outs)
+    loss = sum((o * functional_weights(o.shape, i)).sum() for i, o in enumerate(outs))
+    loss.backward()
+    names = [n for n, _ in tr.named_parameters()]
+    grads = dict(tr.named_parameters())
+    np.savez_compressed(
+        os.path.join(OUT, "g8_transformer_train.npz"), shapes=shapes.numpy(),
+        **{f"feat{i}": f.detach().numpy() for i, f in enumerate(feats)},
+        **{f"pos{i}": f.numpy() for i, f in enumerate(pos)},
+        **{f"mask{i}": f.numpy() for i, f in enumerate(masks)},
+        dn_label=dn_label.detach().numpy(), dn_box=dn_box.detach().numpy(), attn_mask=attn_mask.numpy(),
+        **{f"out{i}": o.detach().numpy() for i, o in enumerate(outs)},
+        loss=np.float64(loss.item()),
+        grad_names=np.array(names),
+        grad_norms=np.array([0.0 if grads[n].grad is None else grads[n].grad.double().norm().item() for n in names]),
+        **{f"grad.{n}": grads[n].grad.numpy() for n in G8_FULL_GRADS},
+        grad_feat3=feats[3].grad.numpy(), grad_feat0_norm=np.float64(feats[0].grad.double().norm().item()),
+        grad_dn_label=dn_label.grad.numpy(), grad_dn_box=dn_box.grad.numpy())
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["g8"]:
+        torch.manual_seed(0)
+        torch.set_num_threads(4)
+        golden_g8(import_reference()[2])
+    else:
+        main()

@@ -297,8 +297,8 @@ class RelationTransformerDecoder(nn.Module):
 
 
 class RelationTransformer(nn.Module):
-    """Two-stage transformer, eval path: pyramids -> (layer class logits [Ld,B,N,C], layer boxes [Ld,B,N,4],
-    encoder top-k class logits [B,N,C], encoder top-k boxes [B,N,4])."""
+    """Two-stage transformer (relation_transformer.py:17-160): pyramids -> decoder layer outputs + encoder proposals, plus
+    the hybrid (one-to-many) branch and the denoising-query concatenation when training."""
 
     def __init__(self, encoder: RelationTransformerEncoder, decoder: RelationTransformerDecoder, num_classes: int,
                  num_feature_levels: int = 4, two_stage_num_proposals: int = 900, hybrid_num_proposals: int = 900):
@@ -306,6 +306,7 @@ class RelationTransformer(nn.Module):
         d = encoder.embed_dim
         self.embed_dim, self.num_feature_levels = d, num_feature_levels
         self.two_stage_num_proposals, self.num_classes = two_stage_num_proposals, num_classes
+        self.hybrid_num_proposals = hybrid_num_proposals
         self.level_embeds = nn.Parameter(torch.empty(num_feature_levels, d))
         self.enc_output = nn.Linear(d, d)
         self.enc_output_norm = nn.LayerNorm(d)
@@ -313,7 +314,7 @@ class RelationTransformer(nn.Module):
         self.tgt_embed = nn.Embedding(two_stage_num_proposals, d)
         self.encoder_class_head = nn.Linear(d, num_classes)
         self.encoder_bbox_head = MLP(d, d, 4, 3)
-        # training-only heads of the hybrid branch: kept so that reference checkpoints load strictly
+        # heads of the hybrid (one-to-many) branch, used in training mode only
         self.hybrid_tgt_embed = nn.Embedding(hybrid_num_proposals, d)
         self.hybrid_class_head = nn.Linear(d, num_classes)
         self.hybrid_bbox_head = MLP(d, d, 4, 3)
@@ -396,7 +397,13 @@ class RelationTransformer(nn.Module):
         return add_norm(self.enc_output_norm, self.enc_output(out)), logit
 
     def forward(self, multi_level_feats: Sequence[Tensor], multi_level_masks: Sequence[Tensor],
-                multi_level_pos_embeds: Sequence[Tensor]):
+                multi_level_pos_embeds: Sequence[Tensor], noised_label_query: Tensor = None, noised_box_query: Tensor = None,
+                attn_mask: Tensor = None):
+        """relation_transformer.py:59-160, same arguments and the same 8 results: (layer class logits [Ld,B,N,C], layer
+        boxes [Ld,B,N,4], encoder top-k logits, encoder top-k boxes, hybrid layer logits, hybrid layer boxes, hybrid
+        encoder logits, hybrid encoder boxes) -- the last four are None unless the module is in training mode.
+        ``noised_label_query [B,Ndn,d]`` / ``noised_box_query [B,Ndn,4]`` (logit space) are the denoising queries put in
+        front of the matching queries (:120-123), ``attn_mask [Ndn+N, Ndn+N]`` bool their visibility mask."""
         mask = self.flatten_levels(multi_level_masks)
         fusion_buffer = None
         if self._fast(multi_level_feats[0]):
@@ -418,18 +425,36 @@ class RelationTransformer(nn.Module):
                               level_start_index=start, reference_points=reference, fusion_buffer=fusion_buffer)
 
         out_memory, out_proposals = self.encoder_output(memory, proposals, mask)
-        enc_class = self.encoder_class_head(out_memory)
-        enc_coord = (self.encoder_bbox_head(out_memory).float() + out_proposals).sigmoid()      # fp32 boxes, no mixed-dtype add
-        k = self.two_stage_num_proposals
-        top = torch.topk(ops.row_max(enc_class) if self._fast(enc_class) else enc_class.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
-        enc_class = enc_class.gather(1, top.expand(-1, -1, self.num_classes))
-        enc_coord = enc_coord.gather(1, top.expand(-1, -1, 4))
-
+        enc_class, enc_coord = self._top_proposals(out_memory, out_proposals, self.encoder_class_head, self.encoder_bbox_head,
+                                                   self.two_stage_num_proposals)
         target = self.tgt_embed.weight.expand(feat.shape[0], -1, -1)
-        classes, coords = self.decoder(query=target, value=memory, key_padding_mask=mask,
-                                       reference_points=enc_coord.detach(), spatial_shapes=shapes,
-                                       level_start_index=start, valid_ratios=valid_ratios)
-        return classes, coords, enc_class, enc_coord
+        reference_points = enc_coord.detach()
+
+        hybrid_enc_class = hybrid_enc_coord = hybrid_classes = hybrid_coords = None
+        if self.training:                               # one-to-many branch: its own heads, queries and proposal count (:101-115)
+            hybrid_enc_class, hybrid_enc_coord = self._top_proposals(out_memory, out_proposals, self.hybrid_class_head,
+                                                                     self.hybrid_bbox_head, self.hybrid_num_proposals)
+            hybrid_target = self.hybrid_tgt_embed.weight.expand(feat.shape[0], -1, -1)
+
+        if noised_label_query is not None and noised_box_query is not None:
+            target = torch.cat([noised_label_query.to(target.dtype), target], 1)
+            reference_points = torch.cat([noised_box_query.sigmoid().to(reference_points.dtype), reference_points], 1)
+
+        classes, coords = self.decoder(query=target, value=memory, key_padding_mask=mask, reference_points=reference_points,
+                                       spatial_shapes=shapes, level_start_index=start, valid_ratios=valid_ratios,
+                                       attn_mask=attn_mask)
+        if self.training:                               # same decoder weights, no relation bias, no mask (:136-146)
+            hybrid_classes, hybrid_coords = self.decoder(
+                query=hybrid_target, value=memory, key_padding_mask=mask, reference_points=hybrid_enc_coord.detach(),
+                spatial_shapes=shapes, level_start_index=start, valid_ratios=valid_ratios, skip_relation=True)
+        return (classes, coords, enc_class, enc_coord, hybrid_classes, hybrid_coords, hybrid_enc_class, hybrid_enc_coord)
+
+    def _top_proposals(self, out_memory: Tensor, out_proposals: Tensor, class_head: nn.Linear, bbox_head: MLP, k: int):
+        """Class logits and sigmoid boxes of the k best-scoring encoder tokens (:86-96 and :101-111)."""
+        logits = class_head(out_memory)
+        boxes = (bbox_head(out_memory).float() + out_proposals).sigmoid()          # fp32 boxes, no mixed-dtype add
+        top = torch.topk(ops.row_max(logits) if self._fast(logits) else logits.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
+        return logits.gather(1, top.expand(-1, -1, self.num_classes)), boxes.gather(1, top.expand(-1, -1, 4))
 
 
 def build_relation_transformer(num_classes=91, embed_dim=256, num_heads=8, d_ffn=2048, num_levels=4, num_points=4,

@@ -56,3 +56,18 @@ def synthetic_state_dict(reference_state_dict):
             v = 0.7 * np.sin(idx * 0.613 + phase)
         out[name] = torch.from_numpy(v.astype(np.float32)).reshape(ref.shape)
     return out
+
+
+def functional_weights(shape, i: int) -> torch.Tensor:
+    """RNG-free weights of the linear functional g8 differentiates: loss = sum_i <out_i, functional_weights(out_i.shape, i)>
+    (shared by oracle/gen_golden.py and the tests, so the fixture need not store them)."""
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.cos(np.arange(n, dtype=np.float64) * 0.37 + i).astype(np.float32)).reshape(tuple(shape))
+
+
+# parameters whose full gradients g8 stores (all others: their L2 norms)
+G8_FULL_GRADS = ("level_embeds", "tgt_embed.weight", "hybrid_tgt_embed.weight",
+                 "decoder.position_relation_embedding.pos_proj.0.weight", "decoder.position_relation_embedding.pos_proj.0.bias",
+                 "encoder.layers.0.self_attn.sampling_offsets.bias", "encoder.layers.1.self_attn.attention_weights.bias",
+                 "decoder.layers.1.self_attn.in_proj_bias", "decoder.layers.2.cross_attn.sampling_offsets.bias",
+                 "decoder.bbox_head.0.layers.2.bias", "hybrid_class_head.bias", "encoder_class_head.bias")

@@ -111,7 +111,7 @@ def test_bf16_two_group_replay_vs_fp32_full_size(bench):
     def make(net):
         @torch.no_grad()
         def fwd(*t):
-            classes, coords, _, _ = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))
+            classes, coords = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))[:2]
             return select_detections(classes[-1].float(), coords[-1].float(), t[3 * L])
         return fwd
 

@@ -22,7 +22,7 @@ def main():
 
     @torch.no_grad()
     def step():
-        classes, coords, _, _ = net(feats, masks, pos)
+        classes, coords = net(feats, masks, pos)[:2]
         return select_detections(classes[-1].float(), coords[-1].float(), sizes)
 
     for _ in range(3):

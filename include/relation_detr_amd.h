@@ -212,6 +212,24 @@ int rdetr_relation_attention_bf16(const uint16_t *q, const uint16_t *k, const ui
                                   float scale, uint16_t *out, int ldo, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same attention with the relation bias GENERATED INSIDE the kernel from the boxes (SURVEY.md section 8 f1 as written):
+ *   out = softmax(Q K^T * attn_scale + relu(W . sine(box_rel_encoding(src_boxes, tgt_boxes)) + b) [, bool mask]) V
+ * Replaces PositionRelationEmbedding.forward (models/bricks/relation_transformer.py:520-532, box_rel_encoding :481-490,
+ * get_sine_pos_embed position_encoding.py:115-138) TOGETHER WITH the nn.MultiheadAttention call that consumes its result
+ * (:369-374, :452-461): the [B, H, N, M] fp32 bias never exists in HBM.
+ *   q, k, v, ld*, bool_mask, out, ldo   as rdetr_relation_attention_bf16
+ *   src_boxes [B, N, 4], tgt_boxes [B, M, 4]   fp32 cxcywh (query i <-> src box i, key j <-> tgt box j), 16-byte aligned
+ *   proj_weight [H, 4F] fp32 (pos_proj.0.weight), proj_bias [H] fp32 or NULL
+ *   H = 8, D = 32, F = 16 only (RDETR_ERR_UNSUPPORTED otherwise -> materialise the bias with rdetr_relation_bias_f32)
+ * bf16 inference path: the sine features are rounded to bf16 for the MFMA projection and the angles use the hardware
+ * log2 / sin / cos; results are held to the same bound against the fp32 reference as rdetr_relation_attention_bf16. */
+int rdetr_relation_attention_boxes_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, int ldq, int ldk, int ldv,
+                                        const float *src_boxes, const float *tgt_boxes, const float *proj_weight,
+                                        const float *proj_bias, const uint8_t *bool_mask, int B, int H, int D,
+                                        int N, int M, int F, float rel_scale, float temperature, float eps, float attn_scale,
+                                        uint16_t *out, int ldo, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Residual add + LayerNorm over the last dimension, one pass (callers either side of the hot path).
  * Replaces the pairs  x + sublayer(x) -> nn.LayerNorm  of the encoder / decoder layers
  *           models/bricks/relation_transformer.py:262-276 (encoder layer), :452-478 (decoder layer), :360.

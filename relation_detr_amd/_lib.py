@@ -33,6 +33,7 @@ SIGNATURES = {
     "rdetr_relation_bias_ws_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp, _vp],
     "rdetr_bias_softmax_f32": [_vp] * 3 + [_c_int] * 3 + [_vp],
     "rdetr_relation_attention_bf16": [_vp] * 3 + [_c_int] * 3 + [_vp, _vp] + [_c_int] * 5 + [_c_float, _vp, _c_int, _vp],
+    "rdetr_relation_attention_boxes_bf16": [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_int] * 6 + [_c_float] * 4 + [_vp, _c_int, _vp],
     "rdetr_box_refine_f32": [_vp, _c_int, _vp, _c_ll, _c_float, _vp, _vp],
     "rdetr_sine_pos_embed": [_vp, _c_ll, _c_int, _c_int, _c_float, _c_float, _vp, _c_int, _vp],
     "rdetr_zero_masked_rows": [_vp, _vp, _c_ll, _c_int, _c_ll, _vp],

@@ -173,15 +173,17 @@ __global__ __launch_bounds__(kRelWaves *kWave) void relation_bias_kernel(
 struct DimTD {
     double v[16];
 };
-__global__ __launch_bounds__(256) void relation_tables_kernel(const float *__restrict__ boxes, long long nboxes, int K, float scale,
-                                                             float eps, DimTD dim_t, float *__restrict__ tab)
+__global__ __launch_bounds__(256) void relation_tables_kernel(const float *__restrict__ src, long long nsrc, const float *__restrict__ tgt,
+                                                             long long nboxes, int K, float scale, float eps, DimTD dim_t,
+                                                             float *__restrict__ tab)
 {
+    // boxes 0 .. nsrc-1 come from `src`, nsrc .. nboxes-1 from `tgt`: one launch fills both tables (they are adjacent in `tab`)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nboxes * 2 * K) return;
     const int k = (int)(idx % K);
     const int c = (int)((idx / K) % 2);
     const long long box = idx / (2 * K);
-    const float sz = boxes[box * 4 + 2 + c] + eps;
+    const float sz = (box < nsrc ? src[box * 4 + 2 + c] : tgt[(box - nsrc) * 4 + 2 + c]) + eps;
     const double a = log((double)sz) * (double)scale / dim_t.v[k];
     tab[idx * 2] = (float)sin(a);
     tab[idx * 2 + 1] = (float)cos(a);
@@ -396,6 +398,22 @@ extern "C" int rdetr_relation_bias_f32(const float *src, const float *tgt, const
     return launch_status();
 }
 
+namespace rdetr {
+// Per-box sine tables of the two size coordinates for both box sets: workspace = [B*N1 + B*N2][2][F/2][sin, cos] floats.
+int launch_relation_tables(const float *src, const float *tgt, int B, int N1, int N2, int F, float scale, float temperature, float eps,
+                           float *workspace, hipStream_t st)
+{
+    if (F <= 0 || (F & 1) || F > 32) return RDETR_ERR_UNSUPPORTED;
+    DimTD dtd;
+    for (int k = 0; k < 16; ++k) dtd.v[k] = 1.0;
+    for (int k = 0; k < F / 2; ++k) dtd.v[k] = (double)powf(temperature, (float)k * 2.0f / (float)F);
+    const long long n1 = (long long)B * N1, n2 = (long long)B * N2;
+    hipLaunchKernelGGL(relation_tables_kernel, dim3((unsigned)(((n1 + n2) * F + 255) / 256)), dim3(256), 0, st, src, n1, tgt, n1 + n2, F / 2,
+                       scale, eps, dtd, workspace);
+    return launch_status();
+}
+}  // namespace rdetr
+
 extern "C" int rdetr_relation_bias_ws_f32(const float *src, const float *tgt, const float *proj_weight, const float *proj_bias,
                                           int B, int N1, int N2, int Hh, int F, float scale, float temperature, float eps,
                                           float *workspace, float *out, void *stream)
@@ -407,19 +425,14 @@ extern "C" int rdetr_relation_bias_ws_f32(const float *src, const float *tgt, co
     if (!src || !tgt || !proj_weight || !out) return RDETR_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     DimT dt;
-    DimTD dtd;
-    for (int k = 0; k < 16; ++k) { dt.v[k] = dt.inv[k] = 1.f; dtd.v[k] = 1.0; }
+    for (int k = 0; k < 16; ++k) dt.v[k] = dt.inv[k] = 1.f;
     for (int k = 0; k < F / 2; ++k) {
         dt.v[k] = powf(temperature, (float)k * 2.0f / (float)F);
         dt.inv[k] = (float)(1.0 / (double)dt.v[k]);
-        dtd.v[k] = (double)dt.v[k];
     }
-    float *src_tab = workspace, *tgt_tab = workspace + (size_t)B * N1 * 2 * F;
-    const long long n1 = (long long)B * N1, n2 = (long long)B * N2;
-    hipLaunchKernelGGL(relation_tables_kernel, dim3((unsigned)((n1 * F + 255) / 256)), dim3(256), 0, st, src, n1, F / 2, scale, eps, dtd,
-                       src_tab);
-    hipLaunchKernelGGL(relation_tables_kernel, dim3((unsigned)((n2 * F + 255) / 256)), dim3(256), 0, st, tgt, n2, F / 2, scale, eps, dtd,
-                       tgt_tab);
+    const int rc = launch_relation_tables(src, tgt, B, N1, N2, F, scale, temperature, eps, workspace, st);
+    if (rc != RDETR_OK) return rc;
+    const float *src_tab = workspace, *tgt_tab = workspace + (size_t)B * N1 * 2 * F;
     const int rows_per_block = kRelWaves * kRelRows;
     dim3 grid((N2 + kWave - 1) / kWave, (N1 + rows_per_block - 1) / rows_per_block, B), block(kRelWaves * kWave);
     if (grid.y > 65535) return RDETR_ERR_UNSUPPORTED;

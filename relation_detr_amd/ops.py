@@ -443,6 +443,51 @@ def relation_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_he
     return out
 
 
+def relation_attention_boxes(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, src_boxes: torch.Tensor,
+                             tgt_boxes: torch.Tensor, proj_weight: torch.Tensor, proj_bias: Optional[torch.Tensor],
+                             mask: Optional[torch.Tensor] = None, scale: Optional[float] = None, num_pos_feats: int = 16,
+                             temperature: float = 10000.0, rel_scale: float = 100.0, eps: float = 1e-5) -> torch.Tensor:
+    """softmax(Q K^T * scale + relation_bias(src_boxes, tgt_boxes)) V with the bias generated inside the kernel (bf16, 8 heads of
+    32, 16 sine features per coordinate, inference).  q [B,N,C], k / v [B,M,C] bf16 (row-strided views are fine); src_boxes
+    [B,N,4] / tgt_boxes [B,M,4] cxcywh; proj_weight [8, 64(,1,1)], proj_bias [8]; mask bool [N,M] or None -> [B,N,C] bf16."""
+    _require_device(q, k, v, src_boxes, tgt_boxes, proj_weight, proj_bias, mask)
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise _lib.RdetrError("relation_attention_boxes: q, k, v must be bfloat16")
+    B, N, C = q.shape
+    M = k.shape[1]
+    if C % num_heads or k.shape != (B, M, C) or v.shape != (B, M, C):
+        raise _lib.RdetrError("relation_attention_boxes: q [B,N,C], k / v [B,M,C] expected")
+    if tuple(src_boxes.shape) != (B, N, 4) or tuple(tgt_boxes.shape) != (B, M, 4):
+        raise _lib.RdetrError("relation_attention_boxes: src_boxes [B,N,4] and tgt_boxes [B,M,4] expected")
+    D = C // num_heads
+
+    def rows(t, n):
+        if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != n * t.stride(1)):
+            t = t.contiguous()
+        return t, t.stride(1)
+
+    (q, ldq), (k, ldk), (v, ldv) = rows(q, N), rows(k, M), rows(v, M)
+    src = src_boxes.detach().float().contiguous()
+    tgt = tgt_boxes.detach().float().contiguous()
+    w = proj_weight.detach().float().reshape(proj_weight.shape[0], -1).contiguous()
+    if tuple(w.shape) != (num_heads, 4 * num_pos_feats):
+        raise _lib.RdetrError(f"proj_weight must be [{num_heads}, {4 * num_pos_feats}]")
+    pb = None if proj_bias is None else proj_bias.detach().float().contiguous()
+    mask_u8 = None
+    if mask is not None:
+        if tuple(mask.shape) != (N, M):
+            raise _lib.RdetrError("relation_attention_boxes: mask must be [N, M]")
+        mask_u8 = mask.to(torch.uint8).contiguous()
+    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=q.device)
+    st = _lib.load().rdetr_relation_attention_boxes_bf16(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), ldq, ldk, ldv, src.data_ptr(), tgt.data_ptr(), w.data_ptr(),
+        None if pb is None else pb.data_ptr(), None if mask_u8 is None else mask_u8.data_ptr(), B, num_heads, D, N, M,
+        num_pos_feats, float(rel_scale), float(temperature), float(eps), float(scale if scale is not None else D ** -0.5),
+        out.data_ptr(), C, _stream_ptr(q))
+    _lib.check(st, "rdetr_relation_attention_boxes_bf16")
+    return out
+
+
 def box_refine(delta: torch.Tensor, reference: torch.Tensor, eps: float = 1e-3) -> torch.Tensor:
     """sigmoid(delta + inverse_sigmoid(reference)) in one kernel; delta fp32 / bf16, reference fp32 -> fp32."""
     _require_device(delta, reference)

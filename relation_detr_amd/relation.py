@@ -60,6 +60,22 @@ class _RelationBiasFunction(torch.autograd.Function):
         return None, None, gw.view(wshape), gb, None, None, None
 
 
+class DeferredRelationBias:
+    """The relation bias of a decoder layer, not materialised: boxes + projection + the optional denoising visibility mask.
+    ``RelationSelfAttention`` generates it inside its attention kernel when it can (bf16 inference, 8 heads of 32:
+    ``ops.relation_attention_boxes``) and calls ``materialize()`` otherwise.  Made by ``PositionRelationEmbedding.deferred``."""
+
+    def __init__(self, module: "PositionRelationEmbedding", src_boxes: Tensor, tgt_boxes: Tensor, attn_mask: Tensor = None):
+        self.module, self.src_boxes, self.tgt_boxes, self.attn_mask = module, src_boxes, tgt_boxes, attn_mask
+
+    def materialize(self) -> Tensor:
+        """What the reference hands to the next layer (relation_transformer.py:372-374): [B*H, N1, N2] float, -inf where masked."""
+        bias = self.module(self.src_boxes, self.tgt_boxes).flatten(0, 1)
+        if self.attn_mask is not None:
+            bias.masked_fill_(self.attn_mask, float("-inf"))
+        return bias
+
+
 class PositionRelationEmbedding(nn.Module):
     def __init__(self, embed_dim=256, num_heads=8, temperature=10000.0, scale=100.0, activation_layer=nn.ReLU,
                  inplace=True):
@@ -80,6 +96,13 @@ class PositionRelationEmbedding(nn.Module):
         conv = self.pos_proj[0]
         return _RelationBiasFunction.apply(src_boxes.detach(), tgt_boxes.detach(), conv.weight, conv.bias,
                                            self.num_pos_feats, self.temperature, self.scale)
+
+    def deferred(self, src_boxes: Tensor, tgt_boxes: Tensor = None, attn_mask: Tensor = None) -> DeferredRelationBias:
+        """Not in the reference: the same bias as a recipe, for an attention kernel that generates it on the fly."""
+        tgt_boxes = src_boxes if tgt_boxes is None else tgt_boxes
+        torch._assert(src_boxes.shape[-1] == 4, "src_boxes much have 4 coordinates")
+        torch._assert(tgt_boxes.shape[-1] == 4, "tgt_boxes must have 4 coordinates")
+        return DeferredRelationBias(self, src_boxes.detach(), tgt_boxes.detach(), attn_mask)
 
 
 PositionRelationEncoder = PositionRelationEmbedding      # the name BASELINE.json's north_star uses

@@ -19,6 +19,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import ops
+from .relation import DeferredRelationBias
 
 
 class _BiasSoftmaxFunction(torch.autograd.Function):
@@ -41,7 +42,7 @@ class _BiasSoftmaxFunction(torch.autograd.Function):
 class RelationSelfAttention(nn.Module):
     """``forward(query, key, value, attn_mask=None, need_weights=False) -> (output, None)`` with
     batch-first ``[B, N, C]`` tensors; ``attn_mask``: float ``[B*H, N, N]`` additive bias (may hold
-    -inf), bool ``[N, N]`` (True = masked) or None."""
+    -inf), bool ``[N, N]`` (True = masked), None, or a ``DeferredRelationBias`` (the bias as a recipe)."""
 
     def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0, batch_first: bool = True):
         super().__init__()
@@ -73,6 +74,19 @@ class RelationSelfAttention(nn.Module):
             k = F.linear(key, self.in_proj_weight[C:2 * C], self.in_proj_bias[C:2 * C])
         v = F.linear(value, self.in_proj_weight[2 * C:], self.in_proj_bias[2 * C:])
         needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+        if isinstance(attn_mask, DeferredRelationBias):
+            rel = attn_mask
+            conv = rel.module.pos_proj[0]
+            if (q.is_cuda and q.dtype == torch.bfloat16 and d == 32 and H == 8 and rel.module.num_pos_feats == 16 and not needs_grad
+                    and not (torch.is_grad_enabled() and conv.weight.requires_grad)
+                    and tuple(rel.src_boxes.shape) == (B, N, 4) and tuple(rel.tgt_boxes.shape) == (B, M, 4)
+                    and (rel.attn_mask is None or rel.attn_mask.dtype == torch.bool and tuple(rel.attn_mask.shape) == (N, M))):
+                # inference, bf16: the bias is generated inside the attention kernel (csrc/attn_rel.hip), never materialised
+                ctx = ops.relation_attention_boxes(q, k, v, H, rel.src_boxes, rel.tgt_boxes, conv.weight, conv.bias, rel.attn_mask,
+                                                   1.0 / math.sqrt(d), rel.module.num_pos_feats, rel.module.temperature,
+                                                   rel.module.scale)
+                return self.out_proj(ctx), None
+            attn_mask = rel.materialize()
         if (q.is_cuda and q.dtype == torch.bfloat16 and d == 32 and not needs_grad
                 and (attn_mask is None or attn_mask.dtype == torch.bool and attn_mask.dim() == 2
                      or attn_mask.dtype != torch.bool and attn_mask.numel() == B * H * N * M)):

@@ -289,9 +289,14 @@ class RelationTransformerDecoder(nn.Module):
             if not skip_relation:                     # bias for the NEXT layer's self-attention (:369-374)
                 src_boxes = tgt_boxes if idx >= 1 else reference_points
                 tgt_boxes = out_coord
-                pos_relation = self.position_relation_embedding(src_boxes, tgt_boxes).flatten(0, 1)
-                if attn_mask is not None:
-                    pos_relation.masked_fill_(attn_mask, float("-inf"))
+                if (query.is_cuda and query.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                        and hasattr(self.position_relation_embedding, "deferred") and os.environ.get("RDETR_REL_FUSED", "1") != "0"):
+                    # bf16 inference: hand the next layer the recipe; its attention kernel generates the bias (csrc/attn_rel.hip)
+                    pos_relation = self.position_relation_embedding.deferred(src_boxes, tgt_boxes, attn_mask)
+                else:
+                    pos_relation = self.position_relation_embedding(src_boxes, tgt_boxes).flatten(0, 1)
+                    if attn_mask is not None:
+                        pos_relation.masked_fill_(attn_mask, float("-inf"))
             reference_points = refine_boxes(self.bbox_head[idx](query), reference_points.detach())
         return torch.stack(classes), torch.stack(coords)
 

@@ -156,10 +156,10 @@ class MultiScaleDeformableAttention(nn.Module):
         _force = os.environ.get("RDETR_MASK_IN_KERNEL")          # A/B aid: "always" / "never"
         if _force and fused and key_padding_mask is not None:
             mask_in_kernel = _force == "always"
-        # encoder shape (queries = the pyramid's own pixels) in bf16: the LDS-window kernel (csrc/msda_win.hip) serves it, and it
-        # fills its windows fastest from a head-major value [B,H,S,D] -- so the projected value is re-laid out once per call,
-        # with the padding zero-fill folded into that pass (no fill pass of its own)
-        head_major = (fused and value.dtype == torch.bfloat16 and query.shape[1] == value.shape[1] and self.num_levels == 4
+        # encoder shape (queries = the pyramid's own pixels) in bf16: the gather runs on a head-major value [B,H,S,D] (contiguous
+        # head planes: 137 -> 115 us at BASELINE.json configs[1]), any level count; the padding zero-fill is
+        # folded into the producer of that layout (no fill pass of its own)
+        head_major = (fused and value.dtype == torch.bfloat16 and query.shape[1] == value.shape[1]
                       and value.shape[1] >= 4096 and os.environ.get("RDETR_VALUE_HEAD_MAJOR", "1") != "0")
         # ... written by the value projection itself where the hand-written projection kernel applies (csrc/linear.hip)
         proj_hm = (head_major and os.environ.get("RDETR_VALUE_PROJ_HM", "1") != "0" and self.value_proj.bias is not None

@@ -209,3 +209,42 @@ def test_window_full_size_properties(ops):
     assert ((o1.float() - d).abs() <= 2.0 ** -7 * d.abs() + 1e-3).all()
     oh = ops.ms_deform_attn_forward(_head_major(v), *dev, value_layout="bhsd", algo="window")
     assert torch.equal(oh, o1)
+
+
+@pytest.mark.parametrize("shapes", [[(56, 72), (28, 36), (14, 18), (7, 9)],                       # 4 levels
+                                    [(64, 80), (32, 40), (16, 20), (8, 10), (4, 5)]])              # 5 levels (FocalNet-style pyramid)
+def test_module_head_major_route_matches_operator_layout_route_and_oracle(shapes, monkeypatch):
+    """MultiScaleDeformableAttention in bf16 eval at the encoder shape (queries = the pyramid's pixels): value_proj writes the
+    head-major layout and the gather reads it (default) -- against the same module with RDETR_VALUE_HEAD_MAJOR=0 (the `_C`
+    layout [B,S,H,D]) and against the fp32 oracle restatement of the module (ms_deform_attn.py:286-377)."""
+    from oracle import torch_ref
+    from relation_detr_amd import MultiScaleDeformableAttention
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    assert S >= 4096
+    torch.manual_seed(L)
+    m = MultiScaleDeformableAttention(256, L, 8, 4).eval()
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(B, S, 256, generator=g) * 0.5
+    pos = torch.randn(B, S, 256, generator=g) * 0.1
+    ref = torch.rand(B, S, L, 2, generator=g)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[1, S // 2::7] = True
+    shp = torch.tensor(shapes, dtype=torch.int64)
+    start = torch.cat([shp.new_zeros(1), (shp[:, 0] * shp[:, 1]).cumsum(0)[:-1]])
+    md = MultiScaleDeformableAttention(256, L, 8, 4).to(DEV).to(torch.bfloat16).eval()
+    md.load_state_dict({k: v.to(torch.bfloat16) for k, v in m.state_dict().items()})
+    args = dict(query=(src + pos).to(DEV).to(torch.bfloat16), reference_points=ref.to(DEV), value=src.to(DEV).to(torch.bfloat16),
+                spatial_shapes=shp.to(DEV), level_start_index=start.to(DEV), key_padding_mask=mask.to(DEV))
+    with torch.no_grad():
+        hm = md(**args).float().cpu()
+        monkeypatch.setenv("RDETR_VALUE_HEAD_MAJOR", "0")
+        plain = md(**args).float().cpu()
+        params = {k: v.to(torch.bfloat16).float() for k, v in m.state_dict().items()}          # the bf16-rounded weights, fp32 math
+        want = torch_ref.msda_module_forward(params, (src + pos).to(torch.bfloat16).float(), ref, src.to(torch.bfloat16).float(),
+                                             shp, start, mask, 8, L, 4)
+    scale = want.abs().max().item()
+    assert (hm - plain).abs().max().item() <= 2.0 ** -6 * scale                 # two bf16 GEMM routes for value_proj
+    assert (hm - want).abs().max().item() <= 2.0 ** -5 * scale                  # 4 bf16 GEMMs + bf16 value / output storage
+    assert ((hm - want).abs().mean() / want.abs().mean()).item() <= 2.0 ** -7

@@ -38,11 +38,16 @@ template <bool LN>
 __global__ __launch_bounds__(kFfnThreads) void ffn_k256_kernel(const uint16_t *__restrict__ x, long long ldx,
                                                                const uint16_t *__restrict__ packed, const uint16_t *__restrict__ b1,
                                                                const uint16_t *__restrict__ b2,
-                                                               long long M, int F, uint16_t *__restrict__ out, long long ldo, int dbg,
+                                                               long long M, int F, uint16_t *__restrict__ out, long long ldo, int dbg_arg,
                                                                const uint16_t *__restrict__ gamma, const uint16_t *__restrict__ beta,
                                                                float eps, const uint16_t *__restrict__ pos, long long ldp,
                                                                uint16_t *__restrict__ out2, long long ldo2)
 {
+#ifdef RDETR_DEV
+    const int dbg = dbg_arg;                 // development builds: component-timing mask (1 no weight stream, 2 no barrier, 4 / 8 no GEMM 2 / 1)
+#else
+    constexpr int dbg = 0;                   // product build: no branches inside the MFMA loop (they end the scheduling regions)
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char ffn_lds[];
     float *b1l = reinterpret_cast<float *>(ffn_lds + 2 * kFfnBufBytes);      // [F]
     float *b2l = b1l + F;                                                     // [256]
@@ -93,59 +98,86 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_k256_kernel(const uint16_t *_
         for (int c = 0; c < nchunks; ++c) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's fragments of chunk c have landed
             if (!(dbg & 2)) __syncthreads();                                  // ... everyone's; and chunk c - 1 is consumed
-            if (c + 1 < nchunks && !(dbg & 1)) issue_chunk(c + 1);
             const u32x4 *w1l = reinterpret_cast<const u32x4 *>(ffn_lds + (c & 1) * kFfnBufBytes);
             const u32x4 *w2l = reinterpret_cast<const u32x4 *>(ffn_lds + (c & 1) * kFfnBufBytes + kFfnW1Bytes);
-            // two tile pairs (32 hidden units each) per chunk, software-pipelined: GEMM 1 of pair 1 is interleaved with GEMM 2 of
-            // pair 0, so that the matrix pipe has independent work while a pair's activations are packed
-            auto gemm1_step = [&](int u, int s, f32x4 (&acc1)[2][2]) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const ffn_bf16x8 a = __builtin_bit_cast(ffn_bf16x8, w1l[((2 * u + e) * 8 + s) * 64 + lane]);
-                    acc1[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, xr[0][s]), acc1[e][0], 0, 0, 0);
-                    acc1[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, xr[1][s]), acc1[e][1], 0, 0, 0);
+            // The chunk is ONE stream of 64 A fragments (32 of W1, 32 of W2), each feeding two MFMAs (the wave's two 16-row blocks):
+            //   t =  0..15  GEMM 1 of tile pair 0                      (k-step t >> 1, tile t & 1)          -> acc1a
+            //   t = 16..47  per k-step s: GEMM 1 of pair 1 (2 fragments -> acc1b), GEMM 2 of pair 0 (out tiles 2s, 2s + 1; B = h0)
+            //   t = 48..63  GEMM 2 of pair 1 (out tile t - 48; B = h1)
+            // read through a ring of three registers, two fragments AHEAD of their use: left to itself the compiler issued every
+            // ds_read_b128 right before its MFMAs and waited lgkmcnt(0) -- the LDS latency once per pair of MFMAs, the matrix pipe
+            // 56 % busy.  The scheduling barriers pin the order; the counted waits follow from it.  The hidden bias is added when a
+            // pair is packed (accumulators start from the inline constant 0: no initialising moves), h0 / h1 are packed two steps
+            // after their last MFMA was issued, behind MFMAs that do not need them.
+            auto frag = [&](int t) -> u32x4 {
+                if (t < 16) return w1l[((t & 1) * 8 + (t >> 1)) * 64 + lane];
+                if (t < 48) {
+                    const int s = (t - 16) >> 2, r = (t - 16) & 3;
+                    return r < 2 ? w1l[((2 + r) * 8 + s) * 64 + lane] : w2l[((2 * s + (r - 2)) * 2) * 64 + lane];
                 }
+                return w2l[((t - 48) * 2 + 1) * 64 + lane];
             };
-            auto gemm2_step = [&](int u, int ot, const u32x4 (&h)[2]) {
-                const ffn_bf16x8 a = __builtin_bit_cast(ffn_bf16x8, w2l[(ot * 2 + u) * 64 + lane]);
-                acc2[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, h[0]), acc2[ot][0], 0, 0, 0);
-                acc2[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ffn_bf16x8, h[1]), acc2[ot][1], 0, 0, 0);
+            f32x4 acc1a[2][2], acc1b[2][2];
+            u32x4 h0[2], h1[2];
+            auto mm = [&](const u32x4 &a, const u32x4 &bq, const f32x4 &cacc) {
+                return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffn_bf16x8, a), __builtin_bit_cast(ffn_bf16x8, bq), cacc, 0, 0, 0);
             };
-            auto init1 = [&](int u, f32x4 (&acc1)[2][2]) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b1l + c * kFfnHC + 32 * u + 8 * g + 4 * e);
-                    acc1[e][0] = b4;
-                    acc1[e][1] = b4;
-                }
-            };
-            auto activate = [&](const f32x4 (&acc1)[2][2], u32x4 (&h)[2]) {   // relu, round to bf16: B operand of GEMM 2, k = 8 g + j
+            auto activate = [&](int u, const f32x4 (&acc1)[2][2], u32x4 (&h)[2]) {   // + bias, round to bf16, relu: B operand of GEMM 2
+                const f32x4 blo = *reinterpret_cast<const f32x4 *>(b1l + c * kFfnHC + 32 * u + 8 * g);
+                const f32x4 bhi = *reinterpret_cast<const f32x4 *>(b1l + c * kFfnHC + 32 * u + 8 * g + 4);
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
-                    const f32x4 lo = acc1[0][cb], hi = acc1[1][cb];
+                    const f32x4 lo = acc1[0][cb] + blo, hi = acc1[1][cb] + bhi;
                     h[cb].x = relu_bf16x2(pack_bf16x2(lo.x, lo.y));          // round, then relu on the packed pair: 2 instructions
                     h[cb].y = relu_bf16x2(pack_bf16x2(lo.z, lo.w));
                     h[cb].z = relu_bf16x2(pack_bf16x2(hi.x, hi.y));
                     h[cb].w = relu_bf16x2(pack_bf16x2(hi.z, hi.w));
                 }
             };
-            f32x4 acc1a[2][2], acc1b[2][2];
-            u32x4 h0[2], h1[2];
-            init1(0, acc1a);
-            if (!(dbg & 8))
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            auto apply = [&](int t, const u32x4 &a) {
+                if (t < 16) {
+                    const int s = t >> 1, e = t & 1;
+                    acc1a[e][0] = mm(a, xr[0][s], s ? acc1a[e][0] : zero4);
+                    acc1a[e][1] = mm(a, xr[1][s], s ? acc1a[e][1] : zero4);
+                } else if (t < 48) {
+                    const int s = (t - 16) >> 2, r = (t - 16) & 3;
+                    if (r < 2) {
+                        acc1b[r][0] = mm(a, xr[0][s], s ? acc1b[r][0] : zero4);
+                        acc1b[r][1] = mm(a, xr[1][s], s ? acc1b[r][1] : zero4);
+                    } else {
+                        const int ot = 2 * s + (r - 2);
+                        acc2[ot][0] = mm(a, h0[0], acc2[ot][0]);
+                        acc2[ot][1] = mm(a, h0[1], acc2[ot][1]);
+                    }
+                } else {
+                    const int ot = t - 48;
+                    acc2[ot][0] = mm(a, h1[0], acc2[ot][0]);
+                    acc2[ot][1] = mm(a, h1[1], acc2[ot][1]);
+                }
+                if (t == 17) activate(0, acc1a, h0);                          // first needed at t = 18
+                if (t == 47) activate(1, acc1b, h1);                          // acc1b complete since t = 45; first needed at t = 48
+            };
+            if (!(dbg & 12)) {
+                u32x4 ring[3];
+                ring[0] = frag(0);
+                ring[1] = frag(1);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) gemm1_step(0, s, acc1a);
-            activate(acc1a, h0);
-            init1(1, acc1b);
+                for (int t = 0; t < 4; ++t) {
+                    ring[(t + 2) % 3] = frag(t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    apply(t, ring[t % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (c + 1 < nchunks && !(dbg & 1)) issue_chunk(c + 1);        // behind the first MFMAs: the pipe starts at once
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (!(dbg & 8)) gemm1_step(1, s, acc1b);
-                if (!(dbg & 4)) { gemm2_step(0, 2 * s, h0); gemm2_step(0, 2 * s + 1, h0); }
+                for (int t = 4; t < 64; ++t) {
+                    if (t + 2 < 64) ring[(t + 2) % 3] = frag(t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    apply(t, ring[t % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            activate(acc1b, h1);
-            if (!(dbg & 4))
-#pragma unroll
-                for (int ot = 0; ot < 16; ++ot) gemm2_step(1, ot, h1);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the epilogue's row pointers (out, pos, out2) are derived from values the compiler cannot see before this point: hoisted
@@ -261,6 +293,12 @@ extern "C" int rdetr_ffn_k256_pack_bf16(const uint16_t *w1, const uint16_t *w2, 
     return launch_status();
 }
 
+#ifdef RDETR_DEV
+// development builds only (make dev): component-timing mask of ffn_k256_kernel (WRONG results)
+static int g_ffn_dbg = 0;
+extern "C" void rdetr_dev_set_ffn_dbg(int v) { g_ffn_dbg = v; }
+#endif
+
 // out[M, 256] = relu(x[M, 256] w1[F, 256]^T + b1[F]) w2[256, F]^T + b2[256] with (w1, w2) packed by rdetr_ffn_k256_pack_bf16; bf16
 // storage, fp32 accumulation, the hidden activations rounded to bf16 (as the unfused path stores them).  F % 64 == 0, <= 4096.
 static int ffn_launch(const uint16_t *x, long long ldx, const uint16_t *packed, const uint16_t *b1, const uint16_t *b2, long long M,
@@ -281,7 +319,11 @@ static int ffn_launch(const uint16_t *x, long long ldx, const uint16_t *packed, 
     if (attr0 != hipSuccess || attr1 != hipSuccess) return RDETR_ERR_LAUNCH;
     const long long ntiles = (M + kFfnWaves * kFfnRows - 1) / (kFfnWaves * kFfnRows);
     const long long gx = ntiles < 256 ? ntiles : 256;
-    const int dbg = 0;                     // component-timing mask of the kernel (development experiments only; the library reads no environment)
+#ifdef RDETR_DEV
+    const int dbg = g_ffn_dbg;
+#else
+    const int dbg = 0;
+#endif
     if (gamma)
         hipLaunchKernelGGL(ffn_k256_kernel<true>, dim3((unsigned)gx), dim3(kFfnThreads), (size_t)lds, static_cast<hipStream_t>(stream), x,
                            ldx, packed, b1, b2, M, F, out, ldo, dbg, gamma, beta, eps, pos, ldp, out2, ldo2);

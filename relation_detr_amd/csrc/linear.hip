@@ -222,21 +222,25 @@ __global__ __launch_bounds__(kLnlThreads) void linear_ln_k256_kernel(const uint1
             xc[1][s] = row_b < M ? *reinterpret_cast<const u32x4 *>(x + row_b * ldx + 32 * s + 8 * g) : u32x4{0u, 0u, 0u, 0u};
         }
         f32x4 acc[16][2];
+        {
+            // one stream of 128 weight fragments (k-step i >> 4, tile i & 15), two MFMAs each, read two fragments ahead through a
+            // ring of three registers with counted LDS waits (csrc/ffn.hip has the story); accumulators start from the inline
+            // constant 0, the bias is added in the epilogue
+            auto frag = [&](int i) -> u32x4 { return wl[((i & 15) * 8 + (i >> 4)) * 64 + lane]; };
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            u32x4 ring[3];
+            ring[0] = frag(0);
+            ring[1] = frag(1);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 32 * (t >> 1) + 8 * g + 4 * (t & 1));
-            acc[t][0] = b4;
-            acc[t][1] = b4;
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const ln_bf16x8 a = __builtin_bit_cast(ln_bf16x8, wl[(t * 8 + s) * 64 + lane]);
-                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[0][s]), acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[1][s]), acc[t][1], 0, 0, 0);
+            for (int i = 0; i < 128; ++i) {
+                if (i + 2 < 128) ring[(i + 2) % 3] = frag(i + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const int s = i >> 4, t = i & 15;
+                const ln_bf16x8 a = __builtin_bit_cast(ln_bf16x8, ring[i % 3]);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[0][s]), s ? acc[t][0] : zero4, 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ln_bf16x8, xc[1][s]), s ? acc[t][1] : zero4, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);                                // one k-step's 16 fragments in flight at a time
         }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -248,6 +252,8 @@ __global__ __launch_bounds__(kLnlThreads) void linear_ln_k256_kernel(const uint1
             for (int u = 0; u < 8; ++u) {
                 const u32x4 r = ok ? *reinterpret_cast<const u32x4 *>(res + row * ldr + 32 * u + 8 * g) : u32x4{0u, 0u, 0u, 0u};
                 f32x4 &lo = acc[2 * u][cb], &hi = acc[2 * u + 1][cb];
+                lo += *reinterpret_cast<const f32x4 *>(bl + 32 * u + 8 * g);
+                hi += *reinterpret_cast<const f32x4 *>(bl + 32 * u + 8 * g + 4);
                 const unsigned p0 = pack_bf16x2(lo.x, lo.y), p1 = pack_bf16x2(lo.z, lo.w), p2 = pack_bf16x2(hi.x, hi.y), p3 = pack_bf16x2(hi.z, hi.w);
                 lo.x = __builtin_bit_cast(float, p0 << 16) + __builtin_bit_cast(float, r.x << 16);
                 lo.y = __builtin_bit_cast(float, p0 & 0xffff0000u) + __builtin_bit_cast(float, r.x & 0xffff0000u);

@@ -248,3 +248,44 @@ def test_module_head_major_route_matches_operator_layout_route_and_oracle(shapes
     assert (hm - plain).abs().max().item() <= 2.0 ** -6 * scale                 # two bf16 GEMM routes for value_proj
     assert (hm - want).abs().max().item() <= 2.0 ** -5 * scale                  # 4 bf16 GEMMs + bf16 value / output storage
     assert ((hm - want).abs().mean() / want.abs().mean()).item() <= 2.0 ** -7
+
+
+def test_head_major_full_size_five_levels(ops):
+    """BASELINE.json configs[4] (FocalNet-L, 1216 x 2016 padded, 5 levels, S = Nq = 204,098, one image): the direct kernel on the
+    head-major value gives the bits it gives on the operator's layout (same arithmetic, other addressing), and a sample of rows
+    agrees with the C oracle."""
+    from oracle import c_oracle
+    shapes = [(304, 504), (152, 252), (76, 126), (38, 63), (19, 32)]
+    shp, start, S = pyramid(shapes)
+    assert S == 204098
+    g = torch.Generator().manual_seed(9)
+    value = torch.randn(1, S, 8, 32, generator=g).to(torch.bfloat16)
+    L = len(shapes)
+    ys = torch.cat([(torch.arange(h * w) // w + 0.5) / h for h, w in shapes])
+    xs = torch.cat([(torch.arange(h * w) % w + 0.5) / w for h, w in shapes])
+    ref = torch.stack([xs, ys], -1)                                                       # every pixel's own centre
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    off = torch.randn(1, S, 8, L, 4, 2, generator=g) * 2.0 / wh.view(1, 1, 1, L, 1, 2)
+    loc = (ref.view(1, S, 1, 1, 1, 2) + off).contiguous()
+    attn = torch.softmax(torch.randn(1, S, 8, L * 4, generator=g), -1).view(1, S, 8, L, 4).contiguous()
+    dv, dl, da = value.to(DEV), loc.to(DEV), attn.to(DEV)
+    a = ops.ms_deform_attn_forward(dv, shp.to(DEV), start.to(DEV), dl, da, algo="direct")
+    b = ops.ms_deform_attn_forward(dv.permute(0, 2, 1, 3).contiguous(), shp.to(DEV), start.to(DEV), dl, da, value_layout="bhsd")
+    assert torch.equal(a, b)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(153216 - 32, 153216 + 32), torch.arange(S - 64, S)])
+    want = c_oracle.msda_forward(value.float().numpy(), shp.numpy(), start.numpy(), loc[:, rows].contiguous().numpy(),
+                                 attn[:, rows].contiguous().numpy())
+    got = b[:, rows.to(DEV)].float().cpu().numpy()
+    assert (np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 1e-3).all()
+
+
+def test_new_entry_points_accept_empty_inputs(ops):
+    """Degenerate sizes of the round-2 entry points: no queries / no rows is a no-op, no keys is refused."""
+    from relation_detr_amd import _lib
+    z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=DEV)
+    boxes0, boxes5 = torch.zeros(2, 0, 4, device=DEV), torch.rand(2, 5, 4, device=DEV)
+    w, b = torch.zeros(8, 64, device=DEV), torch.zeros(8, device=DEV)
+    assert ops.relation_attention_boxes(z(2, 0, 256), z(2, 5, 256), z(2, 5, 256), 8, boxes0, boxes5, w, b).shape == (2, 0, 256)
+    with pytest.raises(_lib.RdetrError):
+        ops.relation_attention_boxes(z(2, 5, 256), z(2, 0, 256), z(2, 0, 256), 8, boxes5, boxes0, w, b)
+    assert ops.value_to_head_major(z(0, 64, 256)).shape == (0, 8, 64, 32)

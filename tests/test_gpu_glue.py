@@ -311,6 +311,16 @@ def test_tokens_from_levels_matches_flatten_transpose_cat(dtype):
     assert out.data_ptr() == wide.data_ptr() and torch.equal(wide[..., :C], want) and not wide[..., C:].any()
     odd = [torch.randn(2, 70, 5, 9, device=DEV).to(dtype)]                        # C and H*W not multiples of the 64 x 64 tile
     assert torch.equal(ops.tokens_from_levels(odd), odd[0].flatten(2).transpose(1, 2))
+    # H*W multiples of 8 (the 16-byte bf16 kernel), with and without a partial last tile, C = 256 and C = 72
+    for C2, shapes2 in ((256, [(20, 28), (10, 20), (5, 8), (2, 4)]), (72, [(16, 24), (3, 8)])):
+        lv = [torch.randn(2, C2, h, w, device=DEV).to(dtype) for h, w in shapes2]
+        em = torch.randn(len(shapes2), C2, device=DEV).to(dtype)
+        assert torch.equal(ops.tokens_from_levels(lv), torch.cat([x.flatten(2).transpose(1, 2) for x in lv], 1))
+        assert torch.equal(ops.tokens_from_levels(lv, add_vecs=list(em)),
+                           torch.cat([x.flatten(2).transpose(1, 2) + e.view(1, 1, -1) for x, e in zip(lv, em)], 1))
+        wide2 = torch.zeros(2, sum(h * w for h, w in shapes2), 3 * C2, device=DEV, dtype=dtype)
+        ops.tokens_from_levels(lv, out=wide2[..., C2:2 * C2])
+        assert torch.equal(wide2[..., C2:2 * C2], torch.cat([x.flatten(2).transpose(1, 2) for x in lv], 1)) and not wide2[..., :C2].any()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -457,8 +457,15 @@ class RelationTransformer(nn.Module):
     def _top_proposals(self, out_memory: Tensor, out_proposals: Tensor, class_head: nn.Linear, bbox_head: MLP, k: int):
         """Class logits and sigmoid boxes of the k best-scoring encoder tokens (:86-96 and :101-111)."""
         logits = class_head(out_memory)
+        if self._fast(logits):
+            # inference: the box head is per token, so it runs on the k selected tokens instead of all S (the reference computes all
+            # boxes and gathers, :88-96 -- same values, 3 GEMMs on 900 rows instead of 22,323 per image)
+            top = torch.topk(ops.row_max(logits), k, dim=1)[1].unsqueeze(-1)
+            sel = out_memory.gather(1, top.expand(-1, -1, out_memory.shape[-1]))
+            boxes = (bbox_head(sel).float() + out_proposals.gather(1, top.expand(-1, -1, 4))).sigmoid()
+            return logits.gather(1, top.expand(-1, -1, self.num_classes)), boxes
         boxes = (bbox_head(out_memory).float() + out_proposals).sigmoid()          # fp32 boxes, no mixed-dtype add
-        top = torch.topk(ops.row_max(logits) if self._fast(logits) else logits.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
+        top = torch.topk(logits.max(-1)[0], k, dim=1)[1].unsqueeze(-1)
         return logits.gather(1, top.expand(-1, -1, self.num_classes)), boxes.gather(1, top.expand(-1, -1, 4))
 
 

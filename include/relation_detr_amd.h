@@ -292,6 +292,17 @@ int rdetr_sine_pos_embed(const float *pos, long long rows, int n, int F, float t
 int rdetr_zero_masked_rows(void *x, const unsigned char *mask, long long rows, int row_bytes, long long ld_bytes,
                            void *stream);
 int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long ldx, void *out, void *stream);
+
+/* Pyramid geometry of the two-stage transformer in two launches (the torch sequences are ~40 small launches per forward):
+ *   valid_ratios [B, L, 2]    unpadded fraction of each level's width / height         models/bricks/base_transformer.py:42-51
+ *   reference    [B, S, L, 2] every position's centre, scaled by the valid ratios      base_transformer.py:57-70
+ *   logit        [B, S, 4]    inverse sigmoid of the position's proposal box (centre, 0.05 * 2^level), +inf where the proposal
+ *                             is not inside (0.01, 0.99) or the position is padded      relation_transformer.py:162-176
+ *   keep         [B, S]       1 / 0 (fp32 or bf16): the factor the encoder memory is multiplied with before enc_output
+ * level_masks: L HOST pointers to the levels' DEVICE bool masks [B, h_l, w_l]; level_hw: 2 L host ints (h, w); pad_mask
+ * [B, S] u8 (the flattened masks) or NULL.  L <= 8. */
+int rdetr_pyramid_points(const unsigned char *const *level_masks, const int *level_hw, int L, int B, const unsigned char *pad_mask,
+                         int keep_is_bf16, float *valid_ratios, float *reference, float *logit, void *keep, void *stream);
 int rdetr_nchw_to_tokens(const void *src, const void *add_vec, int is_bf16, int B, int C, int P,
                          long long out_image_stride, long long ld_out, void *out, void *stream);
 

@@ -168,9 +168,100 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_bf16_vec_kernel(const uint
     }
 }
 
+// ---- pyramid geometry of the two-stage transformer in two launches (torch: ~40 small ones per forward) ---------------------
+struct PyrLevels {
+    const unsigned char *mask[8];     // [B, h, w] bool per level
+    int h[8], w[8], start[8];
+};
+
+// valid_ratios[b][l] = (unpadded columns of row 0 / w, unpadded rows of column 0 / h)   (base_transformer.py:42-51)
+__global__ __launch_bounds__(64) void valid_ratios_kernel(PyrLevels lv, int L, float *__restrict__ out)
+{
+    const int l = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int h = lv.h[l], w = lv.w[l];
+    const unsigned char *m = lv.mask[l] + (size_t)b * h * w;
+    int cw = 0, ch = 0;
+    for (int x = lane; x < w; x += 64) cw += m[x] == 0;
+    for (int y = lane; y < h; y += 64) ch += m[(size_t)y * w] == 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        cw += __shfl_xor(cw, o, 64);
+        ch += __shfl_xor(ch, o, 64);
+    }
+    if (lane == 0) {
+        out[((size_t)b * L + l) * 2 + 0] = (float)cw / (float)w;
+        out[((size_t)b * L + l) * 2 + 1] = (float)ch / (float)h;
+    }
+}
+
+// per position s of level l (pixel x, y):  full = (x + .5, y + .5) / (valid_ratio[b][l] * (w, h))         (base_transformer.py:57-70)
+//   reference[b][s][l'] = full * valid_ratio[b][l']                                                    [B, S, L, 2]
+//   proposal = (full, 0.05 * 2^l, 0.05 * 2^l); valid = all(0.01 < proposal < 0.99) and not padded      (relation_transformer.py:162-176)
+//   logit[b][s] = log(p / (1 - p)), +inf where not valid                                               [B, S, 4]
+//   keep[b][s]  = valid ? 1 : 0 in fp32 / bf16 (the factor the encoder memory is multiplied with)       [B, S]
+template <typename T>
+__global__ __launch_bounds__(256) void pyramid_points_kernel(PyrLevels lv, int L, int S, const float *__restrict__ ratios,
+                                                             const unsigned char *__restrict__ pad, float *__restrict__ reference,
+                                                             float *__restrict__ logit, T *__restrict__ keep)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (s >= S) return;
+    int l = 0;
+    while (l + 1 < L && s >= lv.start[l + 1]) ++l;
+    const int w = lv.w[l], h = lv.h[l], idx = s - lv.start[l];
+    const int y = idx / w, x = idx - y * w;
+    const float *vr = ratios + (size_t)b * L * 2;
+    const float fx = ((float)x + 0.5f) / (vr[2 * l] * (float)w), fy = ((float)y + 0.5f) / (vr[2 * l + 1] * (float)h);
+    float *r = reference + ((size_t)b * S + s) * L * 2;
+    for (int k = 0; k < L; ++k) {
+        r[2 * k] = fx * vr[2 * k];
+        r[2 * k + 1] = fy * vr[2 * k + 1];
+    }
+    const float wh = 0.05f * (float)(1 << l);
+    const float p[4] = {fx, fy, wh, wh};
+    bool ok = !(pad && pad[(size_t)b * S + s]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ok = ok && p[k] > 0.01f && p[k] < 0.99f;
+    float *lg = logit + ((size_t)b * S + s) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lg[k] = ok ? logf(p[k] / (1.0f - p[k])) : __builtin_inff();
+    glue_store<T>(keep + (size_t)b * S + s, ok ? 1.0f : 0.0f);
+}
+
 }  // namespace rdetr
 
 using namespace rdetr;
+
+extern "C" int rdetr_pyramid_points(const unsigned char *const *level_masks, const int *level_hw, int L, int B,
+                                    const unsigned char *pad_mask, int keep_is_bf16, float *valid_ratios, float *reference,
+                                    float *logit, void *keep, void *stream)
+{
+    if (L <= 0 || B < 0 || !level_masks || !level_hw) return RDETR_ERR_INVALID_ARG;
+    if (L > 8 || B > 65535) return RDETR_ERR_UNSUPPORTED;
+    if (B == 0) return RDETR_OK;
+    if (!valid_ratios || !reference || !logit || !keep) return RDETR_ERR_INVALID_ARG;
+    PyrLevels lv;
+    long long S = 0;
+    for (int l = 0; l < L; ++l) {
+        if (!level_masks[l] || level_hw[2 * l] <= 0 || level_hw[2 * l + 1] <= 0) return RDETR_ERR_INVALID_ARG;
+        lv.mask[l] = level_masks[l];
+        lv.h[l] = level_hw[2 * l];
+        lv.w[l] = level_hw[2 * l + 1];
+        lv.start[l] = (int)S;
+        S += (long long)lv.h[l] * lv.w[l];
+    }
+    if (S >= (1ll << 31)) return RDETR_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(valid_ratios_kernel, dim3((unsigned)L, (unsigned)B), dim3(64), 0, st, lv, L, valid_ratios);
+    const dim3 grid((unsigned)((S + 255) / 256), (unsigned)B);
+    if (keep_is_bf16)
+        hipLaunchKernelGGL((pyramid_points_kernel<uint16_t>), grid, dim3(256), 0, st, lv, L, (int)S, valid_ratios, pad_mask, reference, logit,
+                           static_cast<uint16_t *>(keep));
+    else
+        hipLaunchKernelGGL((pyramid_points_kernel<float>), grid, dim3(256), 0, st, lv, L, (int)S, valid_ratios, pad_mask, reference, logit,
+                           static_cast<float *>(keep));
+    return launch_status();
+}
 
 extern "C" int rdetr_box_refine_f32(const void *delta, int delta_is_bf16, const float *ref, long long n, float eps, float *out,
                                     void *stream)

@@ -558,6 +558,35 @@ def row_max(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pyramid_points(level_masks, pad_mask: Optional[torch.Tensor], keep_dtype: torch.dtype):
+    """(valid_ratios [B,L,2], reference points [B,S,L,2], proposal logits [B,S,4], keep [B,S]) of a padded pyramid in two
+    launches (base_transformer.py:42-70, relation_transformer.py:162-176).  level_masks: bool [B,h_l,w_l] per level; pad_mask:
+    their flattening [B,S] or None; keep_dtype float32 | bfloat16."""
+    import ctypes
+    _require_device(*level_masks, pad_mask)
+    L, B = len(level_masks), level_masks[0].shape[0]
+    masks = [m.contiguous() for m in level_masks]
+    if any(m.dtype != torch.bool or m.dim() != 3 or m.shape[0] != B for m in masks) or keep_dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.RdetrError("pyramid_points: bool masks [B, h, w] per level, keep in float32 or bfloat16")
+    S = sum(m.shape[1] * m.shape[2] for m in masks)
+    dev = masks[0].device
+    pad = None
+    if pad_mask is not None:
+        if tuple(pad_mask.shape) != (B, S) or pad_mask.dtype != torch.bool:
+            raise _lib.RdetrError("pyramid_points: pad_mask must be bool [B, S]")
+        pad = pad_mask.contiguous()
+    ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in masks])
+    hw = (ctypes.c_int * (2 * L))(*[v for m in masks for v in (m.shape[1], m.shape[2])])
+    ratios = torch.empty(B, L, 2, dtype=torch.float32, device=dev)
+    reference = torch.empty(B, S, L, 2, dtype=torch.float32, device=dev)
+    logit = torch.empty(B, S, 4, dtype=torch.float32, device=dev)
+    keep = torch.empty(B, S, dtype=keep_dtype, device=dev)
+    st = _lib.load().rdetr_pyramid_points(ptrs, hw, L, B, None if pad is None else pad.data_ptr(), int(keep_dtype == torch.bfloat16),
+                                          ratios.data_ptr(), reference.data_ptr(), logit.data_ptr(), keep.data_ptr(), _stream_ptr(ratios))
+    _lib.check(st, "rdetr_pyramid_points")
+    return ratios, reference, logit, keep
+
+
 def tokens_from_levels(levels, add_vecs=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Level-packed tokens of a feature pyramid: ``cat([x.flatten(2).transpose(1, 2) (+ add_vecs[l]) for x in levels], 1)``
     (base_transformer.py:17-23; the optional per-channel vectors are the level embeddings, relation_transformer.py:87-89).

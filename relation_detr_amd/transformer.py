@@ -422,14 +422,24 @@ class RelationTransformer(nn.Module):
         else:
             feat = self.flatten_levels(multi_level_feats)
             pos = self.flatten_levels([p + e.view(1, -1, 1, 1) for p, e in zip(multi_level_pos_embeds, self.level_embeds)])
-        geo, valid_ratios = self.level_misc(multi_level_masks)
+        fast = self._fast(multi_level_feats[0]) and len(multi_level_masks) <= 8 and os.environ.get("RDETR_PYRAMID_POINTS", "1") != "0"
+        if fast:
+            # inference: valid ratios, reference points, proposal logits and the validity factor in two launches (csrc/glue.hip)
+            # instead of ~40 small ones
+            geo = self.level_geometry([tuple(m.shape[-2:]) for m in multi_level_masks], mask.device)
+            valid_ratios, reference, out_proposals, keep = ops.pyramid_points(multi_level_masks, mask, feat.dtype)
+        else:
+            geo, valid_ratios = self.level_misc(multi_level_masks)
+            reference, proposals = self.reference_and_proposals(geo, valid_ratios)
         shapes, start = geo["shapes"], geo["start"]
-        reference, proposals = self.reference_and_proposals(geo, valid_ratios)
 
         memory = self.encoder(query=feat, query_pos=pos, query_key_padding_mask=mask, spatial_shapes=shapes,
                               level_start_index=start, reference_points=reference, fusion_buffer=fusion_buffer)
 
-        out_memory, out_proposals = self.encoder_output(memory, proposals, mask)
+        if fast:
+            out_memory = add_norm(self.enc_output_norm, self.enc_output(memory * keep.unsqueeze(-1)))
+        else:
+            out_memory, out_proposals = self.encoder_output(memory, proposals, mask)
         enc_class, enc_coord = self._top_proposals(out_memory, out_proposals, self.encoder_class_head, self.encoder_bbox_head,
                                                    self.two_stage_num_proposals)
         target = self.tgt_embed.weight.expand(feat.shape[0], -1, -1)

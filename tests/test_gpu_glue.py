@@ -483,3 +483,36 @@ def test_packed_weight_caches_survive_model_replacement():
         assert (fused_ln - plain_ln).abs().max().item() < 0.15 and (fused_ln - plain_ln).abs().mean().item() < 1e-2
     # the two models really differ (a stale cache would reproduce the first model's outputs)
     assert (first[0] - second[0]).abs().mean().item() > 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pyramid_points_matches_the_torch_sequences(dtype):
+    """rdetr_pyramid_points against the harness's own torch restatement of base_transformer.py:42-70 and
+    relation_transformer.py:162-176 (level_misc, reference_and_proposals, encoder_output): valid ratios and keep mask exactly,
+    reference points and proposal logits to fp32 rounding."""
+    from relation_detr_amd import ops
+    from relation_detr_amd.transformer import RelationTransformer
+    shapes = [(20, 34), (10, 17), (5, 9), (3, 5)]
+    B = 3
+    masks = []
+    for h, w in shapes:
+        m = torch.zeros(B, h, w, dtype=torch.bool, device=DEV)
+        m[1, :, int(round(w * 0.75)):] = True
+        m[2, int(round(h * 0.6)):, :] = True
+        m[2, :, int(round(w * 0.9)):] = True
+        masks.append(m)
+    flat = torch.cat([m.flatten(1) for m in masks], 1)
+    geo, vr = RelationTransformer.level_misc(masks)
+    ref, prop = RelationTransformer.reference_and_proposals(geo, vr)
+    valid = ((prop > 0.01) & (prop < 0.99)).all(-1, keepdim=True)
+    logit = torch.log(prop / (1 - prop)).masked_fill(flat.unsqueeze(-1) | ~valid, float("inf"))
+    keep = (~flat.unsqueeze(-1)) & valid
+    g_vr, g_ref, g_logit, g_keep = ops.pyramid_points(masks, flat, dtype)
+    assert torch.equal(g_vr, vr)
+    assert g_keep.dtype == dtype and torch.equal(g_keep.float(), keep.squeeze(-1).float())
+    assert torch.equal(torch.isinf(g_logit), torch.isinf(logit))
+    fin = ~torch.isinf(logit)
+    assert (g_logit[fin] - logit[fin]).abs().max().item() <= 2e-6
+    assert (g_ref - ref).abs().max().item() <= 2e-7
+    a, b_, c, d = ops.pyramid_points(masks, None, dtype)                       # no padding mask: validity from the proposals alone
+    assert torch.equal(a, vr) and torch.equal(b_, g_ref) and torch.equal(d.float(), valid.squeeze(-1).float())

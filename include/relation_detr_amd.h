@@ -293,6 +293,16 @@ int rdetr_zero_masked_rows(void *x, const unsigned char *mask, long long rows, i
                            void *stream);
 int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long ldx, void *out, void *stream);
 
+/* query_pos = a * scale and query + query_pos (models/bricks/relation_transformer.py:346-347, 452) in one pass over n contiguous
+ * elements (fp32 or bf16); the product is rounded to the storage type before the add, as the two torch kernels it replaces do. */
+int rdetr_scaled_pos(const void *a, const void *scale, const void *query, long long n, int is_bf16, void *pos, void *qp, void *stream);
+
+/* Entry of a decoder layer (models/bricks/relation_transformer.py:335-343) in one launch:
+ *   ref_in [B, N, L, 4] = reference [B, N, 4] * (vr[b][l].x, vr[b][l].y, vr[b][l].x, vr[b][l].y)       valid_ratios vr [B, L, 2]
+ *   emb    [B, N, 4 F]  = get_sine_pos_embed(ref_in[:, :, 0, :], F, temperature, scale, exchange_xy=True)  (fp32 or bf16) */
+int rdetr_decoder_reference(const float *reference, const float *valid_ratios, int B, int N, int L, int F, float temperature,
+                            float scale, float *ref_in, void *emb, int emb_is_bf16, void *stream);
+
 /* Pyramid geometry of the two-stage transformer in two launches (the torch sequences are ~40 small launches per forward):
  *   valid_ratios [B, L, 2]    unpadded fraction of each level's width / height         models/bricks/base_transformer.py:42-51
  *   reference    [B, S, L, 2] every position's centre, scaled by the valid ratios      base_transformer.py:57-70

@@ -66,6 +66,46 @@ __global__ __launch_bounds__(256) void sine_pos_embed_kernel(const float *__rest
 }
 
 
+// Decoder layer entry (relation_transformer.py:335-343): ref_in[b][q][l] = reference[b][q] * (vr[b][l].x, .y, .x, .y) for every
+// level, and the sine embedding of ref_in[:, :, 0, :] (exchange_xy = True) -- one launch for the multiply, the slice copy and the
+// embedding.  One thread per (query, coord, k); the threads with k == 0 also write the coordinate's L scaled values.
+template <typename TO>
+__global__ __launch_bounds__(256) void decoder_reference_kernel(const float *__restrict__ ref, const float *__restrict__ ratios, int N,
+                                                                int L, int F, float scale, GlueDimT dim_t, float *__restrict__ ref_in,
+                                                                TO *__restrict__ emb, long long total)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int half = F / 2;
+    const int k = (int)(idx % half);
+    const long long rc = idx / half;
+    const int c = (int)(rc % 4);
+    const long long row = rc / 4;                         // b * N + q
+    const int b = (int)(row / N);
+    const int src = c == 0 ? 1 : (c == 1 ? 0 : c);        // exchange_xy: output coordinate 0 is y, 1 is x
+    const float *vr = ratios + (size_t)b * L * 2;
+    const float a = ((ref[row * 4 + src] * vr[src & 1]) * scale) / dim_t.v[k];
+    TO *o = emb + (row * 4 + c) * F + 2 * k;
+    glue_store<TO>(o, sinf(a));
+    glue_store<TO>(o + 1, cosf(a));
+    if (k == 0) {
+        const float r = ref[row * 4 + c];
+        for (int l = 0; l < L; ++l) ref_in[(row * L + l) * 4 + c] = r * vr[2 * l + (c & 1)];
+    }
+}
+
+// query_pos = a * s and query + query_pos in one pass (relation_transformer.py:346-347, 452): the product is rounded to the storage
+// type before it is added, as the two torch kernels do.  Contiguous tensors of n elements.
+template <typename T>
+__global__ __launch_bounds__(256) void scaled_pos_kernel(const T *__restrict__ a, const T *__restrict__ sc, const T *__restrict__ q,
+                                                         long long n, T *__restrict__ pos, T *__restrict__ qp)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    glue_store<T>(pos + i, glue_load<T>(a + i) * glue_load<T>(sc + i));
+    glue_store<T>(qp + i, glue_load<T>(q + i) + glue_load<T>(pos + i));
+}
+
 // ---- zero the rows whose mask byte is set ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void zero_masked_rows_kernel(unsigned char *__restrict__ x, const unsigned char *__restrict__ mask,
                                                                long long rows, int row_bytes, long long ld_bytes)
@@ -301,6 +341,47 @@ extern "C" int rdetr_sine_pos_embed(const float *pos, long long rows, int n, int
     else
         hipLaunchKernelGGL((sine_pos_embed_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st, pos, rows, n, F, scale, dt,
                            static_cast<float *>(out));
+    return launch_status();
+}
+
+extern "C" int rdetr_scaled_pos(const void *a, const void *scale, const void *query, long long n, int is_bf16, void *pos, void *qp,
+                                void *stream)
+{
+    if (n < 0) return RDETR_ERR_INVALID_ARG;
+    if (n == 0) return RDETR_OK;
+    if (!a || !scale || !query || !pos || !qp) return RDETR_ERR_INVALID_ARG;
+    const long long nblk = (n + 255) / 256;
+    if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_bf16)
+        hipLaunchKernelGGL((scaled_pos_kernel<uint16_t>), dim3((unsigned)nblk), dim3(256), 0, st, static_cast<const uint16_t *>(a),
+                           static_cast<const uint16_t *>(scale), static_cast<const uint16_t *>(query), n, static_cast<uint16_t *>(pos),
+                           static_cast<uint16_t *>(qp));
+    else
+        hipLaunchKernelGGL((scaled_pos_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st, static_cast<const float *>(a),
+                           static_cast<const float *>(scale), static_cast<const float *>(query), n, static_cast<float *>(pos),
+                           static_cast<float *>(qp));
+    return launch_status();
+}
+
+extern "C" int rdetr_decoder_reference(const float *reference, const float *valid_ratios, int B, int N, int L, int F, float temperature,
+                                       float scale, float *ref_in, void *emb, int emb_is_bf16, void *stream)
+{
+    if (B < 0 || N < 0 || L <= 0 || F <= 0) return RDETR_ERR_INVALID_ARG;
+    if ((F & 1) || F > 128) return RDETR_ERR_UNSUPPORTED;
+    if (B == 0 || N == 0) return RDETR_OK;
+    if (!reference || !valid_ratios || !ref_in || !emb) return RDETR_ERR_INVALID_ARG;
+    GlueDimT dt;
+    for (int k = 0; k < F / 2; ++k) dt.v[k] = powf(temperature, 2.0f * (float)k / (float)F);
+    const long long total = (long long)B * N * 4 * (F / 2), nblk = (total + 255) / 256;
+    if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (emb_is_bf16)
+        hipLaunchKernelGGL((decoder_reference_kernel<uint16_t>), dim3((unsigned)nblk), dim3(256), 0, st, reference, valid_ratios, N, L, F,
+                           scale, dt, ref_in, static_cast<uint16_t *>(emb), total);
+    else
+        hipLaunchKernelGGL((decoder_reference_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st, reference, valid_ratios, N, L, F, scale,
+                           dt, ref_in, static_cast<float *>(emb), total);
     return launch_status();
 }
 

@@ -558,6 +558,40 @@ def row_max(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def scaled_pos(a: torch.Tensor, scale: torch.Tensor, query: torch.Tensor):
+    """``(a * scale, query + a * scale)`` in one pass (same rounding as the two torch kernels); same-shape fp32 | bf16 tensors."""
+    _require_device(a, scale, query)
+    if a.dtype not in (torch.float32, torch.bfloat16) or scale.dtype != a.dtype or query.dtype != a.dtype or scale.shape != a.shape \
+            or query.shape != a.shape:
+        raise _lib.RdetrError("scaled_pos: three tensors of one shape and dtype (float32 or bfloat16)")
+    a, scale, query = a.contiguous(), scale.contiguous(), query.contiguous()
+    pos, qp = torch.empty_like(a), torch.empty_like(a)
+    st = _lib.load().rdetr_scaled_pos(a.data_ptr(), scale.data_ptr(), query.data_ptr(), a.numel(), int(a.dtype == torch.bfloat16),
+                                      pos.data_ptr(), qp.data_ptr(), _stream_ptr(a))
+    _lib.check(st, "rdetr_scaled_pos")
+    return pos, qp
+
+
+def decoder_reference(reference_points: torch.Tensor, valid_ratios: torch.Tensor, num_pos_feats: int = 128, temperature: float = 10000.0,
+                      scale: float = 6.283185307179586, dtype: torch.dtype = torch.float32):
+    """(ref_in [B,N,L,4] fp32, sine embedding of ref_in[:, :, 0, :] [B,N,4*num_pos_feats] in ``dtype``) from the decoder's reference
+    boxes [B,N,4] fp32 and the valid ratios [B,L,2] fp32: relation_transformer.py:335-343 in one launch."""
+    _require_device(reference_points, valid_ratios)
+    if (reference_points.dtype != torch.float32 or valid_ratios.dtype != torch.float32 or reference_points.dim() != 3
+            or reference_points.shape[-1] != 4 or valid_ratios.dim() != 3 or valid_ratios.shape[-1] != 2
+            or valid_ratios.shape[0] != reference_points.shape[0] or dtype not in (torch.float32, torch.bfloat16)):
+        raise _lib.RdetrError("decoder_reference: reference [B,N,4] fp32, valid_ratios [B,L,2] fp32")
+    ref, vr = reference_points.contiguous(), valid_ratios.contiguous()
+    B, N, _ = ref.shape
+    L = vr.shape[1]
+    ref_in = torch.empty(B, N, L, 4, dtype=torch.float32, device=ref.device)
+    emb = torch.empty(B, N, 4 * num_pos_feats, dtype=dtype, device=ref.device)
+    st = _lib.load().rdetr_decoder_reference(ref.data_ptr(), vr.data_ptr(), B, N, L, num_pos_feats, float(temperature), float(scale),
+                                             ref_in.data_ptr(), emb.data_ptr(), int(dtype == torch.bfloat16), _stream_ptr(ref))
+    _lib.check(st, "rdetr_decoder_reference")
+    return ref_in, emb
+
+
 def pyramid_points(level_masks, pad_mask: Optional[torch.Tensor], keep_dtype: torch.dtype):
     """(valid_ratios [B,L,2], reference points [B,S,L,2], proposal logits [B,S,4], keep [B,S]) of a padded pyramid in two
     launches (base_transformer.py:42-70, relation_transformer.py:162-176).  level_masks: bool [B,h_l,w_l] per level; pad_mask:

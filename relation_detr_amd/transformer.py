@@ -224,8 +224,9 @@ class RelationTransformerDecoderLayer(nn.Module):
         nn.init.xavier_uniform_(self.linear2.weight)
 
     def forward(self, query, query_pos, reference_points, value, spatial_shapes, level_start_index, self_attn_mask=None,
-                key_padding_mask=None):
-        qp = query + query_pos
+                key_padding_mask=None, query_plus_pos=None):
+        """``query_plus_pos`` (not in the reference's signature, optional): ``query + query_pos`` if the caller already has it."""
+        qp = query + query_pos if query_plus_pos is None else query_plus_pos
         query = add_norm(self.norm2, query, self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask,
                                                            need_weights=False)[0])
         cross = self.cross_attn(query=query + query_pos, reference_points=reference_points, value=value,
@@ -266,18 +267,26 @@ class RelationTransformerDecoder(nn.Module):
         pos_relation = attn_mask
         tgt_boxes = None
         for idx, layer in enumerate(self.layers):
-            ref_in = reference_points.detach()[:, :, None] * ratio_scale            # [B,N,L,4]
-            if ref_in.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16):
-                from . import ops
-                emb = ops.sine_pos_embed(ref_in[:, :, 0, :].float(), self.embed_dim // 2, dtype=query.dtype)
+            if (reference_points.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16)
+                    and reference_points.dtype == torch.float32 and valid_ratios.dtype == torch.float32
+                    and os.environ.get("RDETR_DECODER_ENTRY", "1") != "0"):
+                # inference: the scaling by the valid ratios, the level-0 slice and its sine embedding in one launch (csrc/glue.hip)
+                ref_in, emb = ops.decoder_reference(reference_points.detach(), valid_ratios, self.embed_dim // 2, dtype=query.dtype)
             else:
+                ref_in = reference_points.detach()[:, :, None] * ratio_scale        # [B,N,L,4]
                 emb = sine_pos_embed(ref_in[:, :, 0, :], self.embed_dim // 2).to(query.dtype)
             query_pos = self.ref_point_head(emb)
+            qpp = None
             if idx != 0:
-                query_pos = query_pos * self.query_scale(query)
+                if query.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16) \
+                        and query_pos.dtype == query.dtype and os.environ.get("RDETR_DECODER_ENTRY", "1") != "0":
+                    query_pos, qpp = ops.scaled_pos(query_pos, self.query_scale(query), query)      # the product and query + product
+                else:
+                    query_pos = query_pos * self.query_scale(query)
             query = layer(query=query, query_pos=query_pos, reference_points=ref_in, value=value,
                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                          key_padding_mask=key_padding_mask, self_attn_mask=pos_relation)
+                          key_padding_mask=key_padding_mask, self_attn_mask=pos_relation,
+                          **({} if qpp is None else {"query_plus_pos": qpp}))
             normed = add_norm(self.norm, query)
             out_class = self.class_head[idx](normed)
             # boxes stay fp32 whatever the network dtype (a bf16 + fp32 add takes torch's slow mixed-dtype kernel)

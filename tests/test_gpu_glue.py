@@ -516,3 +516,22 @@ def test_pyramid_points_matches_the_torch_sequences(dtype):
     assert (g_ref - ref).abs().max().item() <= 2e-7
     a, b_, c, d = ops.pyramid_points(masks, None, dtype)                       # no padding mask: validity from the proposals alone
     assert torch.equal(a, vr) and torch.equal(b_, g_ref) and torch.equal(d.float(), valid.squeeze(-1).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_entry_kernels_match_the_torch_sequences(dtype):
+    """rdetr_decoder_reference / rdetr_scaled_pos against the decoder's own torch statements (relation_transformer.py:335-347)."""
+    from relation_detr_amd import ops
+    from relation_detr_amd.transformer import sine_pos_embed
+    g = torch.Generator().manual_seed(4)
+    B, N, L = 3, 77, 4
+    ref = torch.rand(B, N, 4, generator=g).to(DEV)
+    vr = (torch.rand(B, L, 2, generator=g) * 0.5 + 0.5).to(DEV)
+    ref_in = ref[:, :, None] * torch.cat([vr, vr], -1)[:, None]
+    emb = sine_pos_embed(ref_in[:, :, 0, :], 128)
+    got_ref, got_emb = ops.decoder_reference(ref, vr, 128, dtype=dtype)
+    assert torch.equal(got_ref, ref_in)
+    assert got_emb.dtype == dtype and (got_emb.float() - emb).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2.0 ** -8)
+    a, s, q = (torch.randn(B, N, 256, generator=g).to(dtype).to(DEV) for _ in range(3))
+    pos, qp = ops.scaled_pos(a, s, q)
+    assert torch.equal(pos, a * s) and torch.equal(qp, q + a * s)

@@ -293,6 +293,12 @@ int rdetr_zero_masked_rows(void *x, const unsigned char *mask, long long rows, i
                            void *stream);
 int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long ldx, void *out, void *stream);
 
+/* PostProcess after its top-k (models/bricks/post_process.py:30-44) in one launch: for rank r of image b
+ *   out[b][r] = (x1, y1, x2, y2, score, label) with box = boxes[b][index / C] (cxcywh in [0, 1]) converted to xyxy and scaled by the
+ *   image's (w, h), label = index % C.   score fp32 [B, K], index int64 [B, K], boxes fp32 [B, N, 4], image_sizes int64 [B, 2] (h, w). */
+int rdetr_detections_from_topk(const float *score, const long long *index, const float *boxes, const long long *image_sizes, int B,
+                               int N, int C, int K, float *out, void *stream);
+
 /* query_pos = a * scale and query + query_pos (models/bricks/relation_transformer.py:346-347, 452) in one pass over n contiguous
  * elements (fp32 or bf16); the product is rounded to the storage type before the add, as the two torch kernels it replaces do. */
 int rdetr_scaled_pos(const void *a, const void *scale, const void *query, long long n, int is_bf16, void *pos, void *qp, void *stream);

@@ -106,6 +106,29 @@ __global__ __launch_bounds__(256) void scaled_pos_kernel(const T *__restrict__ a
     glue_store<T>(qp + i, glue_load<T>(q + i) + glue_load<T>(pos + i));
 }
 
+// PostProcess after its top-k (models/bricks/post_process.py:30-44): flat index -> (box, label), cxcywh -> xyxy, scale to pixels,
+// pack (x1, y1, x2, y2, score, label) -- one launch for ~12 torch ones.  sizes: (h, w) per image as int64.
+__global__ __launch_bounds__(256) void detections_kernel(const float *__restrict__ score, const long long *__restrict__ idx,
+                                                         const float *__restrict__ boxes, const long long *__restrict__ sizes, int N, int C,
+                                                         int K, long long total, float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;        // (image, rank)
+    if (i >= total) return;
+    const int b = (int)(i / K);
+    const long long flat = idx[i];
+    const long long bi = flat / C;
+    const float label = (float)(flat - bi * C);
+    const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + ((size_t)b * N + bi) * 4);
+    const float ih = (float)sizes[2 * b], iw = (float)sizes[2 * b + 1];
+    float *o = out + i * 6;
+    o[0] = (bx.x - 0.5f * bx.z) * iw;
+    o[1] = (bx.y - 0.5f * bx.w) * ih;
+    o[2] = (bx.x + 0.5f * bx.z) * iw;
+    o[3] = (bx.y + 0.5f * bx.w) * ih;
+    o[4] = score[i];
+    o[5] = label;
+}
+
 // ---- zero the rows whose mask byte is set ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void zero_masked_rows_kernel(unsigned char *__restrict__ x, const unsigned char *__restrict__ mask,
                                                                long long rows, int row_bytes, long long ld_bytes)
@@ -341,6 +364,20 @@ extern "C" int rdetr_sine_pos_embed(const float *pos, long long rows, int n, int
     else
         hipLaunchKernelGGL((sine_pos_embed_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st, pos, rows, n, F, scale, dt,
                            static_cast<float *>(out));
+    return launch_status();
+}
+
+extern "C" int rdetr_detections_from_topk(const float *score, const long long *index, const float *boxes, const long long *image_sizes,
+                                          int B, int N, int C, int K, float *out, void *stream)
+{
+    if (B < 0 || N <= 0 || C <= 0 || K < 0) return RDETR_ERR_INVALID_ARG;
+    if (B == 0 || K == 0) return RDETR_OK;
+    if (!score || !index || !boxes || !image_sizes || !out) return RDETR_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(boxes) % 16) return RDETR_ERR_UNSUPPORTED;
+    const long long total = (long long)B * K, nblk = (total + 255) / 256;
+    if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(detections_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), score, index, boxes,
+                       image_sizes, N, C, K, total, out);
     return launch_status();
 }
 

@@ -558,6 +558,22 @@ def row_max(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def detections_from_topk(score: torch.Tensor, index: torch.Tensor, boxes: torch.Tensor, image_sizes: torch.Tensor, num_classes: int):
+    """[B,K,6] = (x1, y1, x2, y2, score, label) from PostProcess's top-k (post_process.py:30-44): score fp32 [B,K], index int64 [B,K]
+    into the flattened [N * C] scores, boxes fp32 [B,N,4] cxcywh, image_sizes int64 [B,2] (h, w)."""
+    _require_device(score, index, boxes, image_sizes)
+    B, K = score.shape
+    if (score.dtype != torch.float32 or index.dtype != torch.int64 or boxes.dtype != torch.float32 or image_sizes.dtype != torch.int64
+            or tuple(index.shape) != (B, K) or boxes.dim() != 3 or boxes.shape[0] != B or boxes.shape[2] != 4 or tuple(image_sizes.shape) != (B, 2)):
+        raise _lib.RdetrError("detections_from_topk: score fp32 [B,K], index int64 [B,K], boxes fp32 [B,N,4], image_sizes int64 [B,2]")
+    score, index, boxes, image_sizes = score.contiguous(), index.contiguous(), boxes.contiguous(), image_sizes.contiguous()
+    out = torch.empty(B, K, 6, dtype=torch.float32, device=score.device)
+    st = _lib.load().rdetr_detections_from_topk(score.data_ptr(), index.data_ptr(), boxes.data_ptr(), image_sizes.data_ptr(), B,
+                                                boxes.shape[1], num_classes, K, out.data_ptr(), _stream_ptr(score))
+    _lib.check(st, "rdetr_detections_from_topk")
+    return out
+
+
 def scaled_pos(a: torch.Tensor, scale: torch.Tensor, query: torch.Tensor):
     """``(a * scale, query + a * scale)`` in one pass (same rounding as the two torch kernels); same-shape fp32 | bf16 tensors."""
     _require_device(a, scale, query)

@@ -227,9 +227,15 @@ class RelationTransformerDecoderLayer(nn.Module):
                 key_padding_mask=None, query_plus_pos=None):
         """``query_plus_pos`` (not in the reference's signature, optional): ``query + query_pos`` if the caller already has it."""
         qp = query + query_pos if query_plus_pos is None else query_plus_pos
-        query = add_norm(self.norm2, query, self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask,
-                                                           need_weights=False)[0])
-        cross = self.cross_attn(query=query + query_pos, reference_points=reference_points, value=value,
+        attn = self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask, need_weights=False)[0]
+        if (query.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16)
+                and query_pos.dtype == query.dtype and query_pos.shape == query.shape and os.environ.get("RDETR_DECODER_LN_POS", "1") != "0"):
+            # inference: norm2 and the cross-attention's `query + query_pos` from one pass (csrc/layernorm.hip)
+            query, cross_q = ops.add_layer_norm(attn, query, self.norm2.weight, self.norm2.bias, self.norm2.eps, pos=query_pos)
+        else:
+            query = add_norm(self.norm2, query, attn)
+            cross_q = query + query_pos
+        cross = self.cross_attn(query=cross_q, reference_points=reference_points, value=value,
                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                 key_padding_mask=key_padding_mask)
         query = add_norm(self.norm1, query, cross)
@@ -510,6 +516,9 @@ def select_detections(logits: Tensor, boxes: Tensor, image_sizes: Tensor, k: int
     the tensor `dist.gather_detections` all-gathers."""
     B, N, C = logits.shape
     score, idx = torch.topk(logits.sigmoid().view(B, -1), k, dim=1)
+    if (logits.is_cuda and score.dtype == torch.float32 and boxes.dtype == torch.float32 and image_sizes.dtype == torch.int64
+            and os.environ.get("RDETR_DETECTIONS_KERNEL", "1") != "0"):
+        return ops.detections_from_topk(score, idx, boxes, image_sizes, C)       # the rest of this function in one launch
     box_idx = torch.div(idx, C, rounding_mode="trunc")
     label = idx % C
     cx, cy, w, h = boxes.gather(1, box_idx.unsqueeze(-1).expand(-1, -1, 4)).unbind(-1)

@@ -535,3 +535,19 @@ def test_decoder_entry_kernels_match_the_torch_sequences(dtype):
     a, s, q = (torch.randn(B, N, 256, generator=g).to(dtype).to(DEV) for _ in range(3))
     pos, qp = ops.scaled_pos(a, s, q)
     assert torch.equal(pos, a * s) and torch.equal(qp, q + a * s)
+
+
+def test_detections_kernel_is_the_torch_sequence_bit_for_bit(monkeypatch):
+    """select_detections on the device (rdetr_detections_from_topk after torch.topk) against its own torch statements
+    (post_process.py:30-44), which tests/test_postprocess.py pins to the reference's sequence on the CPU."""
+    from relation_detr_amd.transformer import select_detections
+    g = torch.Generator().manual_seed(12)
+    B, N, C = 3, 900, 91
+    logits = (torch.randn(B, N, C, generator=g) * 2).to(DEV)
+    logits[0, :5, 3] = 7.5                                               # ties among the top scores
+    boxes = torch.cat([torch.rand(B, N, 2, generator=g), torch.rand(B, N, 2, generator=g) * 0.5], -1).to(DEV)
+    sizes = torch.tensor([[800, 1333], [640, 480], [1216, 2016]], device=DEV)
+    got = select_detections(logits, boxes, sizes)
+    monkeypatch.setenv("RDETR_DETECTIONS_KERNEL", "0")
+    want = select_detections(logits, boxes, sizes)
+    assert got.shape == (B, 300, 6) and torch.equal(got, want)

@@ -293,6 +293,18 @@ int rdetr_zero_masked_rows(void *x, const unsigned char *mask, long long rows, i
                            void *stream);
 int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long ldx, void *out, void *stream);
 
+/* The decoder's box head and box refinement in one kernel (bf16 activations, embed_dim 256):
+ *   out = sigmoid(W3 relu(W2 relu(W1 x + b1) + b2) + b3 + inverse_sigmoid(reference))
+ * Replaces bbox_head[i] = MLP(256, 256, 4, 3) (models/bricks/basic.py:6-24, relation_transformer.py:294) followed by the
+ * refinement of relation_transformer.py:363-381 (inverse_sigmoid: util/misc.py:31-35), for the layer's two calls at once:
+ *   xa [M, 256] -> out_a [M, 4] (the layer's boxes, from norm(query)),  xb [M, 256] or NULL -> out_b (the next reference points)
+ *   pw1, pw2   the hidden weights [256, 256] packed by rdetr_linear_pack_k256_bf16;  b1, b2 [256], w3 [4, 256], b3 [4]   bf16
+ *   reference  fp32 [M, 4] (shared by both inputs), eps of inverse_sigmoid;  outputs fp32.  lda / ldb: row strides in elements.
+ * Hidden activations and the final delta are rounded to bf16 where the unfused path stores them. */
+int rdetr_box_head_k256_bf16(const uint16_t *xa, long long lda, const uint16_t *xb, long long ldb, const uint16_t *pw1,
+                             const uint16_t *b1, const uint16_t *pw2, const uint16_t *b2, const uint16_t *w3, const uint16_t *b3,
+                             const float *reference, float eps, long long M, float *out_a, float *out_b, void *stream);
+
 /* PostProcess after its top-k (models/bricks/post_process.py:30-44) in one launch: for rank r of image b
  *   out[b][r] = (x1, y1, x2, y2, score, label) with box = boxes[b][index / C] (cxcywh in [0, 1]) converted to xyxy and scaled by the
  *   image's (w, h), label = index % C.   score fp32 [B, K], index int64 [B, K], boxes fp32 [B, N, 4], image_sizes int64 [B, 2] (h, w). */

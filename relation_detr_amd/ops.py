@@ -558,6 +558,52 @@ def row_max(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _packed_k256(weight: torch.Tensor) -> torch.Tensor:
+    """[256, 256] bf16 weight in MFMA-fragment order (rdetr_linear_pack_k256_bf16), cached until the tensor changes or dies."""
+    def build():
+        packed = torch.empty(256 * 256, dtype=torch.bfloat16, device=weight.device)
+        st = _lib.load().rdetr_linear_pack_k256_bf16(weight.data_ptr(), packed.data_ptr(), _stream_ptr(weight))
+        _lib.check(st, "rdetr_linear_pack_k256_bf16")
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(weight.device).synchronize()
+        return packed
+    return _LINEAR_PACKED.get((weight,), build)
+
+
+def box_head_k256_supported(x: torch.Tensor, layers) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and len(layers) == 3
+            and tuple(layers[0].weight.shape) == (256, 256) and tuple(layers[1].weight.shape) == (256, 256)
+            and tuple(layers[2].weight.shape) == (4, 256) and all(l.bias is not None and l.weight.dtype == torch.bfloat16
+                                                                  and l.weight.is_contiguous() and l.weight.data_ptr() % 16 == 0 for l in layers))
+
+
+def box_head_k256(xa: torch.Tensor, xb: Optional[torch.Tensor], layers, reference: torch.Tensor, eps: float = 1e-3):
+    """``sigmoid(MLP3(x) + inverse_sigmoid(reference))`` for the decoder's box head (three nn.Linear: 256 -> 256 -> 256 -> 4, ReLU
+    between) on one or two bf16 [..., 256] inputs sharing the fp32 reference boxes [..., 4]: one kernel instead of 3 (6) GEMMs
+    and 1 (2) refine launches (relation_transformer.py:294, 363-381).  Returns fp32 boxes (a pair when ``xb`` is given)."""
+    _require_device(xa, xb, reference)
+    if not box_head_k256_supported(xa, layers) or reference.dtype != torch.float32 or reference.shape[-1] != 4:
+        raise _lib.RdetrError("box_head_k256: bf16 [..., 256] inputs, Linear(256,256), Linear(256,256), Linear(256,4) in bf16, fp32 reference")
+    rows, _, lda = _rows_view(xa, "box_head_k256")
+    ldb = 0
+    if xb is not None:
+        if xb.shape != xa.shape or xb.dtype != xa.dtype:
+            raise _lib.RdetrError("box_head_k256: the two inputs must have one shape and dtype")
+        _, _, ldb = _rows_view(xb, "box_head_k256")
+    ref = reference.contiguous()
+    if ref.numel() != rows * 4:
+        raise _lib.RdetrError("box_head_k256: reference must hold one box per input row")
+    pw1, pw2 = _packed_k256(layers[0].weight), _packed_k256(layers[1].weight)
+    out_a = torch.empty_like(ref)
+    out_b = torch.empty_like(ref) if xb is not None else None
+    st = _lib.load().rdetr_box_head_k256_bf16(
+        xa.data_ptr(), lda, None if xb is None else xb.data_ptr(), ldb, pw1.data_ptr(), layers[0].bias.contiguous().data_ptr(),
+        pw2.data_ptr(), layers[1].bias.contiguous().data_ptr(), layers[2].weight.data_ptr(), layers[2].bias.contiguous().data_ptr(),
+        ref.data_ptr(), float(eps), rows, out_a.data_ptr(), None if out_b is None else out_b.data_ptr(), _stream_ptr(xa))
+    _lib.check(st, "rdetr_box_head_k256_bf16")
+    return out_a if xb is None else (out_a, out_b)
+
+
 def detections_from_topk(score: torch.Tensor, index: torch.Tensor, boxes: torch.Tensor, image_sizes: torch.Tensor, num_classes: int):
     """[B,K,6] = (x1, y1, x2, y2, score, label) from PostProcess's top-k (post_process.py:30-44): score fp32 [B,K], index int64 [B,K]
     into the flattened [N * C] scores, boxes fp32 [B,N,4] cxcywh, image_sizes int64 [B,2] (h, w)."""

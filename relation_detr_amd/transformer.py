@@ -269,7 +269,7 @@ class RelationTransformerDecoder(nn.Module):
                 key_padding_mask=None, attn_mask=None, skip_relation=False):
         classes: List[Tensor] = []
         coords: List[Tensor] = []
-        ratio_scale = torch.cat([valid_ratios, valid_ratios], -1)[:, None]          # [B,1,L,4]
+        ratio_scale = None                                                          # [B,1,L,4], built when the torch path needs it
         pos_relation = attn_mask
         tgt_boxes = None
         for idx, layer in enumerate(self.layers):
@@ -279,6 +279,8 @@ class RelationTransformerDecoder(nn.Module):
                 # inference: the scaling by the valid ratios, the level-0 slice and its sine embedding in one launch (csrc/glue.hip)
                 ref_in, emb = ops.decoder_reference(reference_points.detach(), valid_ratios, self.embed_dim // 2, dtype=query.dtype)
             else:
+                if ratio_scale is None:
+                    ratio_scale = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
                 ref_in = reference_points.detach()[:, :, None] * ratio_scale        # [B,N,L,4]
                 emb = sine_pos_embed(ref_in[:, :, 0, :], self.embed_dim // 2).to(query.dtype)
             query_pos = self.ref_point_head(emb)
@@ -295,11 +297,20 @@ class RelationTransformerDecoder(nn.Module):
                           **({} if qpp is None else {"query_plus_pos": qpp}))
             normed = add_norm(self.norm, query)
             out_class = self.class_head[idx](normed)
-            # boxes stay fp32 whatever the network dtype (a bf16 + fp32 add takes torch's slow mixed-dtype kernel)
-            out_coord = refine_boxes(self.bbox_head[idx](normed), reference_points)
+            last = idx == self.num_layers - 1
+            # bf16 inference: the box head on `normed` (this layer's boxes) and on `query` (the next reference points) with both
+            # refinements as ONE kernel (csrc/mlp.hip) instead of 6 GEMMs + 2 launches of the decoder's dependency chain
+            fused_box = (query.is_cuda and not torch.is_grad_enabled() and reference_points.dtype == torch.float32
+                         and os.environ.get("RDETR_BOX_HEAD", "1") != "0" and ops.box_head_k256_supported(normed, self.bbox_head[idx].layers))
+            if fused_box:
+                res = ops.box_head_k256(normed, None if last else query, self.bbox_head[idx].layers, reference_points.detach())
+                out_coord, next_reference = (res, None) if last else res
+            else:
+                # boxes stay fp32 whatever the network dtype (a bf16 + fp32 add takes torch's slow mixed-dtype kernel)
+                out_coord = refine_boxes(self.bbox_head[idx](normed), reference_points)
             classes.append(out_class)
             coords.append(out_coord)
-            if idx == self.num_layers - 1:
+            if last:
                 break
             if not skip_relation:                     # bias for the NEXT layer's self-attention (:369-374)
                 src_boxes = tgt_boxes if idx >= 1 else reference_points
@@ -312,7 +323,7 @@ class RelationTransformerDecoder(nn.Module):
                     pos_relation = self.position_relation_embedding(src_boxes, tgt_boxes).flatten(0, 1)
                     if attn_mask is not None:
                         pos_relation.masked_fill_(attn_mask, float("-inf"))
-            reference_points = refine_boxes(self.bbox_head[idx](query), reference_points.detach())
+            reference_points = next_reference if fused_box else refine_boxes(self.bbox_head[idx](query), reference_points.detach())
         return torch.stack(classes), torch.stack(coords)
 
 

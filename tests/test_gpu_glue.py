@@ -551,3 +551,42 @@ def test_detections_kernel_is_the_torch_sequence_bit_for_bit(monkeypatch):
     monkeypatch.setenv("RDETR_DETECTIONS_KERNEL", "0")
     want = select_detections(logits, boxes, sizes)
     assert got.shape == (B, 300, 6) and torch.equal(got, want)
+
+
+def test_fused_box_head_matches_the_unfused_sequence():
+    """rdetr_box_head_k256_bf16 (csrc/mlp.hip) against the decoder's own statements: bbox_head MLP (three bf16 GEMMs with ReLU,
+    models/bricks/basic.py:6-24) + refine_boxes (relation_transformer.py:363-381), for both inputs of a layer.  Reference
+    arithmetic: fp32 products of the bf16 operands with the activations rounded to bf16 where the unfused path stores them."""
+    from relation_detr_amd import ops
+    from relation_detr_amd.transformer import MLP, inverse_sigmoid
+    torch.manual_seed(5)
+    head = MLP(256, 256, 4, 3).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        head.layers[2].weight.copy_(torch.randn(4, 256) * 0.05)           # the reference initialises the last layer with zeros
+        head.layers[2].bias.copy_(torch.randn(4) * 0.1)
+        for l in head.layers[:2]:
+            l.bias.copy_(torch.randn(256) * 0.1)
+    g = torch.Generator().manual_seed(6)
+    for B, N in ((2, 900), (1, 37), (3, 300)):
+        xa = torch.randn(B, N, 256, generator=g).to(torch.bfloat16).to(DEV)
+        xb = torch.randn(B, N, 256, generator=g).to(torch.bfloat16).to(DEV)
+        ref = torch.rand(B, N, 4, generator=g).to(DEV)
+        ref[0, 0] = torch.tensor([0.0, 1.0, 1e-5, 0.5])                      # the clamps of inverse_sigmoid
+
+        def want(x):
+            h = x.float()
+            for i, l in enumerate(head.layers):
+                h = h @ l.weight.float().t() + l.bias.float()
+                if i < 2:
+                    h = h.relu()
+                h = h.to(torch.bfloat16).float()
+            return (h + inverse_sigmoid(ref)).sigmoid()
+
+        got_a, got_b = ops.box_head_k256(xa, xb, head.layers, ref)
+        assert got_a.dtype == torch.float32 and got_a.shape == ref.shape
+        for got, x in ((got_a, xa), (got_b, xb)):
+            w = want(x)
+            # one bf16 rounding of a hidden unit can differ by an ulp (summation order): boxes agree to a few 1e-3
+            assert (got - w).abs().max().item() <= 4e-3 and (got - w).abs().mean().item() <= 2e-4
+        only = ops.box_head_k256(xa, None, head.layers, ref)
+        assert torch.equal(only, got_a)

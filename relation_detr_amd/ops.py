@@ -469,10 +469,21 @@ def relation_attention_boxes(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, 
     (q, ldq), (k, ldk), (v, ldv) = rows(q, N), rows(k, M), rows(v, M)
     src = src_boxes.detach().float().contiguous()
     tgt = tgt_boxes.detach().float().contiguous()
-    w = proj_weight.detach().float().reshape(proj_weight.shape[0], -1).contiguous()
-    if tuple(w.shape) != (num_heads, 4 * num_pos_feats):
+    if proj_weight.numel() != num_heads * 4 * num_pos_feats:
         raise _lib.RdetrError(f"proj_weight must be [{num_heads}, {4 * num_pos_feats}]")
-    pb = None if proj_bias is None else proj_bias.detach().float().contiguous()
+    # fp32 copies of the projection (the module holds it in the network dtype), kept until a parameter changes: converted per
+    # call they were two small launches in every decoder layer's dependency chain
+    def f32_copy(t, shape):
+        def build():
+            c = t.detach().float().reshape(shape).contiguous()
+            if c.data_ptr() == t.data_ptr():
+                c = c.clone()                           # an fp32 parameter: the cache must not alias it
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(t.device).synchronize()      # other streams (image groups) pick it up without an event
+            return c
+        return _REL_PROJ_F32.get((t,), build)
+    w = f32_copy(proj_weight, (num_heads, -1))
+    pb = None if proj_bias is None else f32_copy(proj_bias, (-1,))
     mask_u8 = None
     if mask is not None:
         if tuple(mask.shape) != (N, M):
@@ -893,6 +904,7 @@ def ffn_ln_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.T
 
 
 _LINEAR_PACKED = _PackedWeightCache()     # (weight,) -> fragment-order copy
+_REL_PROJ_F32 = _PackedWeightCache()      # (pos_proj weight | bias,) -> fp32 copy
 
 
 def linear_ln_k256_supported(x: torch.Tensor, weight: torch.Tensor, residual: torch.Tensor) -> bool:

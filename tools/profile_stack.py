@@ -34,6 +34,12 @@ def main():
         torch.cuda.synchronize()
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=48,
                                                               max_shapes_column_width=70))
+    # the small torch operators (what is left of the launch chains): calls per step by name and shapes
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0]
+    rows.sort(key=lambda e: -e.count)
+    print("\naten operators with device time, by call count (3 steps):")
+    for e in rows[:60]:
+        print(f"  {e.count:5d} x {e.key:32s} {e.device_time_total / max(e.count, 1):8.1f} us each   {str(e.input_shapes)[:110]}")
 
 
 if __name__ == "__main__":

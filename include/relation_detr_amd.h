@@ -293,6 +293,16 @@ int rdetr_zero_masked_rows(void *x, const unsigned char *mask, long long rows, i
                            void *stream);
 int rdetr_row_max(const void *x, int is_bf16, long long rows, int C, long long ldx, void *out, void *stream);
 
+/* Row-wise top-k (largest, sorted) for the two selections on the transformer's dependency chain:
+ *   torch.topk(enc_outputs_class.max(-1)[0], 900, dim=1)    models/bricks/relation_transformer.py:93 (and :105 for the hybrid branch)
+ *   torch.topk(prob.view(B, -1), 300, dim=1)                models/bricks/post_process.py:30
+ *   x [rows, n] fp32 or bf16, contiguous  ->  values [rows, k] fp32, indices [rows, k] int64
+ * Order: value descending, equal values by index ascending, NaN above everything (torch.topk leaves the order of equal values
+ * unspecified).  1 <= k <= min(n, 1024), n < 2^20.  workspace: rdetr_topk_workspace_bytes(rows, n, k) bytes of scratch, 16-byte
+ * aligned. */
+long long rdetr_topk_workspace_bytes(int rows, int n, int k);
+int rdetr_topk(const void *x, int is_bf16, int rows, int n, int k, void *workspace, float *values, long long *indices, void *stream);
+
 /* The decoder's box head and box refinement in one kernel (bf16 activations, embed_dim 256):
  *   out = sigmoid(W3 relu(W2 relu(W1 x + b1) + b2) + b3 + inverse_sigmoid(reference))
  * Replaces bbox_head[i] = MLP(256, 256, 4, 3) (models/bricks/basic.py:6-24, relation_transformer.py:294) followed by the

@@ -38,6 +38,8 @@ SIGNATURES = {
     "rdetr_sine_pos_embed": [_vp, _c_ll, _c_int, _c_int, _c_float, _c_float, _vp, _c_int, _vp],
     "rdetr_zero_masked_rows": [_vp, _vp, _c_ll, _c_int, _c_ll, _vp],
     "rdetr_row_max": [_vp, _c_int, _c_ll, _c_int, _c_ll, _vp, _vp],
+    "rdetr_topk_workspace_bytes": [_c_int, _c_int, _c_int],
+    "rdetr_topk": [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "rdetr_box_head_k256_bf16": [_vp, _c_ll, _vp, _c_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_float, _c_ll, _vp, _vp, _vp],
     "rdetr_detections_from_topk": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "rdetr_scaled_pos": [_vp, _vp, _vp, _c_ll, _c_int, _vp, _vp, _vp],
@@ -78,7 +80,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "rdetr_status_string" else _c_int
+        fn.restype = ctypes.c_char_p if name == "rdetr_status_string" else (_c_ll if name == "rdetr_topk_workspace_bytes" else _c_int)
     if lib.rdetr_abi_version() != 2:
         raise RdetrError(f"ABI version mismatch: library {lib.rdetr_abi_version()}, binding 2")
     _lib = lib

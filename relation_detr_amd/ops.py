@@ -615,6 +615,31 @@ def box_head_k256(xa: torch.Tensor, xb: Optional[torch.Tensor], layers, referenc
     return out_a if xb is None else (out_a, out_b)
 
 
+def topk_supported(x: torch.Tensor, k: int) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and 1 <= k <= min(x.shape[1], 1024)
+            and x.shape[1] < (1 << 20) and x.shape[0] <= 65535)
+
+
+def topk(x: torch.Tensor, k: int):
+    """``torch.topk(x, k, dim=1)`` (largest, sorted) for fp32 | bf16 x [rows, n]: (values fp32 [rows, k], indices int64 [rows, k]);
+    equal values come out by ascending index, NaN first (csrc/topk.hip).  The two selections on the transformer's chain
+    (relation_transformer.py:93, post_process.py:30)."""
+    _require_device(x)
+    if not topk_supported(x, k):
+        raise _lib.RdetrError("topk: fp32 | bf16 [rows, n] on the device, 1 <= k <= min(n, 1024), n < 2^20")
+    x = x.contiguous()
+    rows, n = x.shape
+    lib = _lib.load()
+    ws = torch.empty(int(lib.rdetr_topk_workspace_bytes(rows, n, k)) + 16, dtype=torch.uint8, device=x.device)
+    values = torch.empty(rows, k, dtype=torch.float32, device=x.device)
+    indices = torch.empty(rows, k, dtype=torch.int64, device=x.device)
+    off = (-ws.data_ptr()) % 16
+    st = lib.rdetr_topk(x.data_ptr(), int(x.dtype == torch.bfloat16), rows, n, k, ws.data_ptr() + off, values.data_ptr(),
+                        indices.data_ptr(), _stream_ptr(x))
+    _lib.check(st, "rdetr_topk")
+    return values, indices
+
+
 def detections_from_topk(score: torch.Tensor, index: torch.Tensor, boxes: torch.Tensor, image_sizes: torch.Tensor, num_classes: int):
     """[B,K,6] = (x1, y1, x2, y2, score, label) from PostProcess's top-k (post_process.py:30-44): score fp32 [B,K], index int64 [B,K]
     into the flattened [N * C] scores, boxes fp32 [B,N,4] cxcywh, image_sizes int64 [B,2] (h, w)."""

@@ -496,7 +496,9 @@ class RelationTransformer(nn.Module):
         if self._fast(logits):
             # inference: the box head is per token, so it runs on the k selected tokens instead of all S (the reference computes all
             # boxes and gathers, :88-96 -- same values, 3 GEMMs on 900 rows instead of 22,323 per image)
-            top = torch.topk(ops.row_max(logits), k, dim=1)[1].unsqueeze(-1)
+            scores = ops.row_max(logits)
+            use_own = os.environ.get("RDETR_TOPK", "1") != "0" and ops.topk_supported(scores, k)
+            top = (ops.topk(scores, k)[1] if use_own else torch.topk(scores, k, dim=1)[1]).unsqueeze(-1)
             sel = out_memory.gather(1, top.expand(-1, -1, out_memory.shape[-1]))
             boxes = (bbox_head(sel).float() + out_proposals.gather(1, top.expand(-1, -1, 4))).sigmoid()
             return logits.gather(1, top.expand(-1, -1, self.num_classes)), boxes
@@ -526,7 +528,12 @@ def select_detections(logits: Tensor, boxes: Tensor, image_sizes: Tensor, k: int
     logits [B,N,C], boxes [B,N,4] cxcywh in [0,1], image_sizes [B,2] (h,w) -> [B,k,6] = (x1,y1,x2,y2,score,label),
     the tensor `dist.gather_detections` all-gathers."""
     B, N, C = logits.shape
-    score, idx = torch.topk(logits.sigmoid().view(B, -1), k, dim=1)
+    prob = logits.sigmoid().view(B, -1)
+    if logits.is_cuda and os.environ.get("RDETR_TOPK", "1") != "0" and ops.topk_supported(prob, k):
+        score, idx = ops.topk(prob, k)                  # equal scores by ascending index (csrc/topk.hip); torch: unspecified
+        score = score.to(prob.dtype)
+    else:
+        score, idx = torch.topk(prob, k, dim=1)
     if (logits.is_cuda and score.dtype == torch.float32 and boxes.dtype == torch.float32 and image_sizes.dtype == torch.int64
             and os.environ.get("RDETR_DETECTIONS_KERNEL", "1") != "0"):
         return ops.detections_from_topk(score, idx, boxes, image_sizes, C)       # the rest of this function in one launch

@@ -590,3 +590,41 @@ def test_fused_box_head_matches_the_unfused_sequence():
             assert (got - w).abs().max().item() <= 4e-3 and (got - w).abs().mean().item() <= 2e-4
         only = ops.box_head_k256(xa, None, head.layers, ref)
         assert torch.equal(only, got_a)
+
+
+@pytest.mark.parametrize("rows,n,k", [(4, 22323, 900), (4, 81900, 300), (2, 22323, 900), (3, 5000, 1024), (1, 4096, 1), (2, 1500, 1500 - 476),
+                                      (5, 33, 33)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_topk_matches_torch_values_and_breaks_ties_by_index(rows, n, k, dtype):
+    """rdetr_topk (csrc/topk.hip): the VALUES are torch.topk's; the indices point at those values; equal values come out by
+    ascending index (torch leaves their order unspecified), which makes the result unique -- checked against a stable sort."""
+    from relation_detr_amd import ops
+    g = torch.Generator().manual_seed(rows * 1000 + k)
+    x = torch.randn(rows, n, generator=g)
+    if dtype == torch.bfloat16:
+        x = (x * 0.05 - 4.0).to(torch.bfloat16)                              # bf16 scores around the class prior: thousands of ties
+    x = x.to(DEV)
+    v, i = ops.topk(x, k)
+    tv, _ = torch.topk(x.float(), k, dim=1)
+    assert v.dtype == torch.float32 and i.dtype == torch.int64 and torch.equal(v, tv)
+    assert torch.equal(x.float().gather(1, i), v)
+    # unique answer: sort by (value descending, index ascending)
+    order = torch.sort(x.float(), dim=1, descending=True, stable=True)[1][:, :k]
+    assert torch.equal(i, order)
+
+
+def test_topk_special_values_and_limits():
+    from relation_detr_amd import _lib, ops
+    x = torch.zeros(2, 5000, device=DEV)                                       # all equal: the first k indices
+    v, i = ops.topk(x, 700)
+    assert torch.equal(i, torch.arange(700, device=DEV).expand(2, -1)) and not v.any()
+    y = torch.randn(1, 1000, device=DEV)
+    y[0, 17] = float("nan"); y[0, 400] = float("inf"); y[0, 5] = float("-inf"); y[0, 800] = float("nan")
+    v, i = ops.topk(y, 1000)                                                  # k == n: a full sort
+    assert i[0, :3].tolist() == [17, 800, 400] and torch.isnan(v[0, :2]).all() and v[0, 2] == float("inf")
+    assert i[0, -1].item() == 5 and v[0, -1] == float("-inf")
+    assert sorted(i[0].tolist()) == list(range(1000))
+    with pytest.raises(_lib.RdetrError):
+        ops.topk(y, 1025)
+    with pytest.raises(_lib.RdetrError):
+        ops.topk(y[:, :10], 11)

@@ -92,48 +92,88 @@ __global__ __launch_bounds__(1024) void topk_scan_kernel(const unsigned *__restr
 }
 
 // C: elements above the boundary bin go to the winners, elements of the boundary bin to the candidates (composites).  grid (chunks, rows)
+// One global atomic per workgroup and class: the 16 items of a thread are classified first, positions inside the workgroup come from
+// a prefix over its threads (a chain of per-wave atomics cost ~1 us each: 16 us per launch).
 __global__ __launch_bounds__(kTkBlock) void topk_partition_kernel(const void *__restrict__ x, int is_bf16, int n, TkCtrl *ctrl,
                                                                  unsigned long long *__restrict__ winners, int k,
                                                                  unsigned long long *__restrict__ cand)
 {
+    __shared__ unsigned wave_w[kTkBlock / 64], wave_c[kTkBlock / 64], base_w, base_c;
     const int r = blockIdx.y;
     const size_t row = (size_t)r * n;
     const unsigned bstar = ctrl[r].bin;
     unsigned long long *w = winners + (size_t)r * k, *c = cand + (size_t)r * n;
-    const int base = blockIdx.x * kTkChunk, lane = threadIdx.x & 63;
+    const int base = blockIdx.x * kTkChunk, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned key[kTkItems];
+    unsigned nw = 0, nc = 0, fw = 0, fc = 0;                              // counts and per-item flags of this thread
+#pragma unroll
     for (int j = 0; j < kTkItems; ++j) {
         const int i = base + j * kTkBlock + threadIdx.x;
-        unsigned key = 0, bin = 0;
-        const bool ok = i < n;
-        if (ok) {
-            key = tk_key(tk_load(x, is_bf16, row + i));
-            bin = key >> 20;
+        key[j] = 0;
+        if (i < n) {
+            key[j] = tk_key(tk_load(x, is_bf16, row + i));
+            const unsigned bin = key[j] >> 20;
+            if (bin > bstar) { fw |= 1u << j; ++nw; }
+            else if (bin == bstar) { fc |= 1u << j; ++nc; }
         }
-        const unsigned long long comp = ((unsigned long long)key << 20) | (unsigned long long)(0xfffffu - (unsigned)i);
-        const bool win = ok && bin > bstar, cd = ok && bin == bstar;
-        // one global atomic per wave and class, positions inside the wave by ballot prefix
-        const unsigned long long mw = __ballot(win), mc = __ballot(cd);
-        unsigned bw = 0, bc = 0;
-        if (lane == 0) {
-            if (mw) bw = atomicAdd(&ctrl[r].out_count, (unsigned)__popcll(mw));
-            if (mc) bc = atomicAdd(&ctrl[r].cand_count, (unsigned)__popcll(mc));
+    }
+    // exclusive prefix of (nw, nc) over the workgroup's threads
+    unsigned pw = nw, pc = nc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned a = __shfl_up(pw, o, 64), bq = __shfl_up(pc, o, 64);
+        if (lane >= o) { pw += a; pc += bq; }
+    }
+    if (lane == 63) { wave_w[wave] = pw; wave_c[wave] = pc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tw = 0, tc = 0;
+        for (int i = 0; i < kTkBlock / 64; ++i) {
+            const unsigned a = wave_w[i], bq = wave_c[i];
+            wave_w[i] = tw; wave_c[i] = tc;
+            tw += a; tc += bq;
         }
-        bw = __shfl(bw, 0, 64);
-        bc = __shfl(bc, 0, 64);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (win) w[bw + __popcll(mw & below)] = comp;
-        if (cd) c[bc + __popcll(mc & below)] = comp;
+        base_w = tw ? atomicAdd(&ctrl[r].out_count, tw) : 0u;
+        base_c = tc ? atomicAdd(&ctrl[r].cand_count, tc) : 0u;
+    }
+    __syncthreads();
+    unsigned ow = base_w + wave_w[wave] + pw - nw, oc = base_c + wave_c[wave] + pc - nc;
+#pragma unroll
+    for (int j = 0; j < kTkItems; ++j) {
+        const int i = base + j * kTkBlock + threadIdx.x;
+        const unsigned long long comp = ((unsigned long long)key[j] << 20) | (unsigned long long)(0xfffffu - (unsigned)i);
+        if (fw >> j & 1u) w[ow++] = comp;
+        if (fc >> j & 1u) c[oc++] = comp;
     }
 }
 
 // D: one workgroup per row.  The `need` = k - above largest composites of the candidates (4 radix passes of 10 bits over the 40 low
 // bits; the 12 high bits are equal in all of them), appended to the winners; bitonic sort of the k winners; values + indices out.
+// Scans run inside the waves (shuffles) with one exchange of the 16 wave totals; the sort's strides below 64 are shuffles too.
+__device__ __forceinline__ unsigned tk_suffix_exclusive(unsigned v, unsigned *wave_tot, int t)
+{
+    // sum of v over the threads ABOVE t in a 1024-thread workgroup
+    const int lane = t & 63, wave = t >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned a = __shfl_down(incl, o, 64);
+        if (lane + o < 64) incl += a;
+    }
+    if (lane == 0) wave_tot[wave] = incl;                                  // the wave's total
+    __syncthreads();
+    unsigned above_waves = 0;
+    for (int wv = wave + 1; wv < 16; ++wv) above_waves += wave_tot[wv];
+    __syncthreads();
+    return incl - v + above_waves;
+}
+
 __global__ __launch_bounds__(1024) void topk_finish_kernel(const TkCtrl *__restrict__ ctrl, const unsigned long long *__restrict__ cand, int n,
                                                           unsigned long long *__restrict__ winners, int k, float *__restrict__ values,
                                                           long long *__restrict__ indices)
 {
     __shared__ unsigned hist[1024];
-    __shared__ unsigned s[1024];
+    __shared__ unsigned wave_tot[16];
     __shared__ unsigned long long keys[1024];
     __shared__ unsigned sel_bin, sel_above, append;
     const int r = blockIdx.x, t = threadIdx.x;
@@ -150,16 +190,9 @@ __global__ __launch_bounds__(1024) void topk_finish_kernel(const TkCtrl *__restr
             if ((v & pmask) == prefix) atomicAdd(&hist[(unsigned)(v >> shift) & 1023u], 1u);
         }
         __syncthreads();
-        s[t] = hist[t];
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {                           // inclusive suffix sums over the 1024 digits
-            const unsigned v = t + o < 1024 ? s[t + o] : 0u;
-            __syncthreads();
-            s[t] += v;
-            __syncthreads();
-        }
-        const unsigned ab = t + 1 < 1024 ? s[t + 1] : 0u;
-        if (ab < need && ab + hist[t] >= need) {
+        const unsigned mine = hist[t];
+        const unsigned ab = tk_suffix_exclusive(mine, wave_tot, t);        // candidates with a larger digit
+        if (ab < need && ab + mine >= need) {
             sel_bin = (unsigned)t;
             sel_above = ab;
         }
@@ -178,27 +211,27 @@ __global__ __launch_bounds__(1024) void topk_finish_kernel(const TkCtrl *__restr
         if ((v & low40) >= prefix) w[above + atomicAdd(&append, 1u)] = v;
     }
     __syncthreads();
-    __threadfence_block();
-    // bitonic sort, descending, of the k winners padded with zeros to 1024
-    keys[t] = t < k ? w[t] : 0ull;
-    __syncthreads();
+    // bitonic sort, descending, of the k winners padded with zeros to 1024: one element per thread, strides < 64 by shuffle
+    unsigned long long mine = t < k ? w[t] : 0ull;
     for (int size = 2; size <= 1024; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int p = t ^ stride;
-            if (p > t) {
-                const bool desc = (t & size) == 0;
-                const unsigned long long a = keys[t], b = keys[p];
-                if ((a < b) == desc) {
-                    keys[t] = b;
-                    keys[p] = a;
-                }
+            unsigned long long other;
+            if (stride >= 64) {
+                keys[t] = mine;
+                __syncthreads();
+                other = keys[t ^ stride];
+                __syncthreads();
+            } else {
+                const unsigned lo = __shfl_xor((unsigned)mine, stride, 64), hi = __shfl_xor((unsigned)(mine >> 32), stride, 64);
+                other = ((unsigned long long)hi << 32) | lo;
             }
-            __syncthreads();
+            const bool desc = (t & size) == 0, lower = (t & stride) == 0;    // the lower thread of a pair keeps the larger value when descending
+            const bool take_max = desc == lower;
+            mine = take_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
         }
     if (t < k) {
-        const unsigned long long v = keys[t];
-        values[(size_t)r * k + t] = tk_value((unsigned)(v >> 20));
-        indices[(size_t)r * k + t] = (long long)(0xfffffu - (unsigned)(v & 0xfffffu));
+        values[(size_t)r * k + t] = tk_value((unsigned)(mine >> 20));
+        indices[(size_t)r * k + t] = (long long)(0xfffffu - (unsigned)(mine & 0xfffffu));
     }
 }
 

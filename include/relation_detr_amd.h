@@ -310,10 +310,13 @@ int rdetr_topk(const void *x, int is_bf16, int rows, int n, int k, void *workspa
  *   xa [M, 256] -> out_a [M, 4] (the layer's boxes, from norm(query)),  xb [M, 256] or NULL -> out_b (the next reference points)
  *   pw1, pw2   the hidden weights [256, 256] packed by rdetr_linear_pack_k256_bf16;  b1, b2 [256], w3 [4, 256], b3 [4]   bf16
  *   reference  fp32 [M, 4] (shared by both inputs), eps of inverse_sigmoid;  outputs fp32.  lda / ldb: row strides in elements.
+ *   reference_is_logit != 0: the reference is in logit space already and is added as it is -- the two-stage proposal boxes
+ *              sigmoid(encoder_bbox_head(output_memory) + output_proposals), relation_transformer.py:88-90
  * Hidden activations and the final delta are rounded to bf16 where the unfused path stores them. */
 int rdetr_box_head_k256_bf16(const uint16_t *xa, long long lda, const uint16_t *xb, long long ldb, const uint16_t *pw1,
                              const uint16_t *b1, const uint16_t *pw2, const uint16_t *b2, const uint16_t *w3, const uint16_t *b3,
-                             const float *reference, float eps, long long M, float *out_a, float *out_b, void *stream);
+                             const float *reference, int reference_is_logit, float eps, long long M, float *out_a, float *out_b,
+                             void *stream);
 
 /* PostProcess after its top-k (models/bricks/post_process.py:30-44) in one launch: for rank r of image b
  *   out[b][r] = (x1, y1, x2, y2, score, label) with box = boxes[b][index / C] (cxcywh in [0, 1]) converted to xyxy and scaled by the

@@ -40,7 +40,7 @@ SIGNATURES = {
     "rdetr_row_max": [_vp, _c_int, _c_ll, _c_int, _c_ll, _vp, _vp],
     "rdetr_topk_workspace_bytes": [_c_int, _c_int, _c_int],
     "rdetr_topk": [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
-    "rdetr_box_head_k256_bf16": [_vp, _c_ll, _vp, _c_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_float, _c_ll, _vp, _vp, _vp],
+    "rdetr_box_head_k256_bf16": [_vp, _c_ll, _vp, _c_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_float, _c_ll, _vp, _vp, _vp],
     "rdetr_detections_from_topk": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "rdetr_scaled_pos": [_vp, _vp, _vp, _c_ll, _c_int, _vp, _vp, _vp],
     "rdetr_decoder_reference": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _vp, _vp, _c_int, _vp],

@@ -29,8 +29,8 @@ constexpr int kMlpLdsBytes = kMlpLdsBias + (2 * 256 + 4) * 4;
 __global__ __launch_bounds__(kMlpThreads) void box_head_k256_kernel(
     const uint16_t *__restrict__ xa, long long lda, const uint16_t *__restrict__ xb, long long ldb, const uint16_t *__restrict__ pw1,
     const uint16_t *__restrict__ b1, const uint16_t *__restrict__ pw2, const uint16_t *__restrict__ b2, const uint16_t *__restrict__ w3,
-    const uint16_t *__restrict__ b3, const float *__restrict__ ref, float eps, long long M, float *__restrict__ out_a,
-    float *__restrict__ out_b)
+    const uint16_t *__restrict__ b3, const float *__restrict__ ref, int ref_is_logit, float eps, long long M,
+    float *__restrict__ out_a, float *__restrict__ out_b)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char mlp_lds[];
     const u32x4 *wl = reinterpret_cast<const u32x4 *>(mlp_lds);
@@ -136,10 +136,14 @@ __global__ __launch_bounds__(kMlpThreads) void box_head_k256_kernel(
             float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float xx = fminf(fmaxf(rv[k], 0.f), 1.f);
-                if (rv[k] != rv[k]) xx = rv[k];
-                const float x1 = fmaxf(xx, eps), x2 = fmaxf(1.f - xx, eps);
-                const float z = bf16_bits_to_f32(f32_to_bf16_bits(dl[k])) + logf(x1 / x2);   // delta as the bf16 the GEMM would store
+                float lg = rv[k];                                             // the reference already in logit space ...
+                if (!ref_is_logit) {                                          // ... or a box: inverse_sigmoid (util/misc.py:31-35)
+                    float xx = fminf(fmaxf(rv[k], 0.f), 1.f);
+                    if (rv[k] != rv[k]) xx = rv[k];
+                    const float x1 = fmaxf(xx, eps), x2 = fmaxf(1.f - xx, eps);
+                    lg = logf(x1 / x2);
+                }
+                const float z = bf16_bits_to_f32(f32_to_bf16_bits(dl[k])) + lg;   // delta as the bf16 the GEMM would store
                 o[k] = 1.f / (1.f + expf(-z));
             }
             *reinterpret_cast<f32x4 *>((r < M ? out_a : out_b) + q * 4) = f32x4{o[0], o[1], o[2], o[3]};
@@ -154,9 +158,11 @@ using namespace rdetr;
 // out_a [M, 4] (and out_b [M, 4] when xb is given) = sigmoid(MLP3(x) + inverse_sigmoid(reference [M, 4])): the decoder's box head
 // and box refinement for one or two [M, 256] bf16 inputs (row strides lda / ldb in elements).  pw1 / pw2: the two [256, 256]
 // hidden weights packed by rdetr_linear_pack_k256_bf16; w3 [4, 256], b1 / b2 [256], b3 [4] bf16; reference / outputs fp32.
+// reference_is_logit != 0: `reference` is added as it is (the two-stage proposals, relation_transformer.py:89-90, come as logits).
 extern "C" int rdetr_box_head_k256_bf16(const uint16_t *xa, long long lda, const uint16_t *xb, long long ldb, const uint16_t *pw1,
                                         const uint16_t *b1, const uint16_t *pw2, const uint16_t *b2, const uint16_t *w3, const uint16_t *b3,
-                                        const float *reference, float eps, long long M, float *out_a, float *out_b, void *stream)
+                                        const float *reference, int reference_is_logit, float eps, long long M, float *out_a, float *out_b,
+                                        void *stream)
 {
     if (M < 0 || lda < 256 || (xb && ldb < 256)) return RDETR_ERR_INVALID_ARG;
     if ((lda & 7) || (xb && (ldb & 7))) return RDETR_ERR_UNSUPPORTED;
@@ -171,6 +177,6 @@ extern "C" int rdetr_box_head_k256_bf16(const uint16_t *xa, long long lda, const
     const long long total = xb ? 2 * M : M, nblk = (total + kMlpWaves * kMlpRows - 1) / (kMlpWaves * kMlpRows);
     if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(box_head_k256_kernel, dim3((unsigned)nblk), dim3(kMlpThreads), kMlpLdsBytes, static_cast<hipStream_t>(stream), xa,
-                       lda, xb, ldb, pw1, b1, pw2, b2, w3, b3, reference, eps, M, out_a, out_b);
+                       lda, xb, ldb, pw1, b1, pw2, b2, w3, b3, reference, reference_is_logit, eps, M, out_a, out_b);
     return launch_status();
 }

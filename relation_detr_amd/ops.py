@@ -588,10 +588,12 @@ def box_head_k256_supported(x: torch.Tensor, layers) -> bool:
                                                                   and l.weight.is_contiguous() and l.weight.data_ptr() % 16 == 0 for l in layers))
 
 
-def box_head_k256(xa: torch.Tensor, xb: Optional[torch.Tensor], layers, reference: torch.Tensor, eps: float = 1e-3):
+def box_head_k256(xa: torch.Tensor, xb: Optional[torch.Tensor], layers, reference: torch.Tensor, eps: float = 1e-3,
+                  reference_is_logit: bool = False):
     """``sigmoid(MLP3(x) + inverse_sigmoid(reference))`` for the decoder's box head (three nn.Linear: 256 -> 256 -> 256 -> 4, ReLU
     between) on one or two bf16 [..., 256] inputs sharing the fp32 reference boxes [..., 4]: one kernel instead of 3 (6) GEMMs
-    and 1 (2) refine launches (relation_transformer.py:294, 363-381).  Returns fp32 boxes (a pair when ``xb`` is given)."""
+    and 1 (2) refine launches (relation_transformer.py:294, 363-381).  ``reference_is_logit``: the reference is added as it is
+    (the two-stage proposals, :88-90).  Returns fp32 boxes (a pair when ``xb`` is given)."""
     _require_device(xa, xb, reference)
     if not box_head_k256_supported(xa, layers) or reference.dtype != torch.float32 or reference.shape[-1] != 4:
         raise _lib.RdetrError("box_head_k256: bf16 [..., 256] inputs, Linear(256,256), Linear(256,256), Linear(256,4) in bf16, fp32 reference")
@@ -610,7 +612,8 @@ def box_head_k256(xa: torch.Tensor, xb: Optional[torch.Tensor], layers, referenc
     st = _lib.load().rdetr_box_head_k256_bf16(
         xa.data_ptr(), lda, None if xb is None else xb.data_ptr(), ldb, pw1.data_ptr(), layers[0].bias.contiguous().data_ptr(),
         pw2.data_ptr(), layers[1].bias.contiguous().data_ptr(), layers[2].weight.data_ptr(), layers[2].bias.contiguous().data_ptr(),
-        ref.data_ptr(), float(eps), rows, out_a.data_ptr(), None if out_b is None else out_b.data_ptr(), _stream_ptr(xa))
+        ref.data_ptr(), int(reference_is_logit), float(eps), rows, out_a.data_ptr(), None if out_b is None else out_b.data_ptr(),
+        _stream_ptr(xa))
     _lib.check(st, "rdetr_box_head_k256_bf16")
     return out_a if xb is None else (out_a, out_b)
 

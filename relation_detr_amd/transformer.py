@@ -500,7 +500,11 @@ class RelationTransformer(nn.Module):
             use_own = os.environ.get("RDETR_TOPK", "1") != "0" and ops.topk_supported(scores, k)
             top = (ops.topk(scores, k)[1] if use_own else torch.topk(scores, k, dim=1)[1]).unsqueeze(-1)
             sel = out_memory.gather(1, top.expand(-1, -1, out_memory.shape[-1]))
-            boxes = (bbox_head(sel).float() + out_proposals.gather(1, top.expand(-1, -1, 4))).sigmoid()
+            prop = out_proposals.gather(1, top.expand(-1, -1, 4))
+            if os.environ.get("RDETR_BOX_HEAD", "1") != "0" and prop.dtype == torch.float32 and ops.box_head_k256_supported(sel, bbox_head.layers):
+                boxes = ops.box_head_k256(sel, None, bbox_head.layers, prop, reference_is_logit=True)      # 3 GEMMs + add + sigmoid
+            else:
+                boxes = (bbox_head(sel).float() + prop).sigmoid()
             return logits.gather(1, top.expand(-1, -1, self.num_classes)), boxes
         boxes = (bbox_head(out_memory).float() + out_proposals).sigmoid()          # fp32 boxes, no mixed-dtype add
         top = torch.topk(logits.max(-1)[0], k, dim=1)[1].unsqueeze(-1)

@@ -590,6 +590,18 @@ def test_fused_box_head_matches_the_unfused_sequence():
             assert (got - w).abs().max().item() <= 4e-3 and (got - w).abs().mean().item() <= 2e-4
         only = ops.box_head_k256(xa, None, head.layers, ref)
         assert torch.equal(only, got_a)
+        # the reference given as a logit (two-stage proposals), +inf where a proposal is invalid -> box 1.0 like torch
+        logit = torch.log(ref.clamp(1e-3, 1 - 1e-3) / (1 - ref.clamp(1e-3, 1 - 1e-3)))
+        logit[0, 1] = float("inf")
+        got_l = ops.box_head_k256(xa, None, head.layers, logit, reference_is_logit=True)
+        h = xa.float()
+        for i, l in enumerate(head.layers):
+            h = h @ l.weight.float().t() + l.bias.float()
+            if i < 2:
+                h = h.relu()
+            h = h.to(torch.bfloat16).float()
+        w = (h + logit).sigmoid()
+        assert (got_l - w).abs().max().item() <= 4e-3 and (got_l[0, 1] == 1.0).all()
 
 
 @pytest.mark.parametrize("rows,n,k", [(4, 22323, 900), (4, 81900, 300), (2, 22323, 900), (3, 5000, 1024), (1, 4096, 1), (2, 1500, 1500 - 476),

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RDETR_ABI_VERSION 3
+#define RDETR_ABI_VERSION 2
 
 typedef enum rdetr_status {
     RDETR_OK = 0,
@@ -114,27 +114,20 @@ int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spati
  *                                    gathered from there on the matrix cores; samples outside their window are fetched from
  *                                    global memory, so results never depend on the windows.  RDETR_ERR_UNSUPPORTED for any
  *                                    other shape.
- *                 RDETR_MSDA_COARSE_LDS  csrc/msda_fwd.hip -- the query-run kernel as a persistent workgroup per (image, head)
- *                                    slice that keeps the planes of levels 2 and 3 in LDS (RDETR_VALUE_BHSD, L == 4; planes
- *                                    above 92 KiB per head stay on the global gathers).  Bit-identical to RDETR_MSDA_DIRECT.
- *                                    RDETR_ERR_UNSUPPORTED for any other layout / level count.
- * Results of the window kernel and the others agree to the rounding of the bf16 output (different summation order). */
+ * Results of the two kernels agree to the rounding of the bf16 output (different summation order). */
 #define RDETR_VALUE_BSHD 0
 #define RDETR_VALUE_BHSD 1
 #define RDETR_MSDA_AUTO 0
 #define RDETR_MSDA_DIRECT 1
 #define RDETR_MSDA_WINDOW 2
-#define RDETR_MSDA_COARSE_LDS 3
-#define RDETR_MSDA_DIRECT_FMA 4
 int rdetr_msda_forward_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
                                 const int64_t *level_start_index, const float *sampling_loc, const float *attn_weight, int B,
-                                int S, int H, int D, int L, int Nq, int P, int algo, const int64_t *spatial_shapes_host,
-                                uint16_t *out, void *stream);
+                                int S, int H, int D, int L, int Nq, int P, int algo, uint16_t *out, void *stream);
 int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
                                       const int64_t *level_start_index, const uint16_t *sampling_offsets, int ld_offsets,
                                       const uint16_t *attn_logits, int ld_logits, const float *reference_points, int ref_dim,
                                       const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
-                                      int algo, const int64_t *spatial_shapes_host, uint16_t *out, void *stream);
+                                      int algo, uint16_t *out, void *stream);
 
 /* Projected value [B, S, H*D] bf16 (rows `ld` elements apart, ld % 8 == 0: the rows may be a column slice of a wider
  * buffer) -> head-major [B, H, S, D], with the rows of padded positions (`key_padding_mask` u8 [B, S], may be NULL)

@@ -25,8 +25,8 @@ SIGNATURES = {
     "rdetr_msda_forward_fused_bf16": [_vp] * 6 + [_c_int] * 8 + [_vp, _vp],
     "rdetr_msda_forward_fused_ex_f32": [_vp] * 4 + [_c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_fused_ex_bf16": [_vp] * 4 + [_c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
-    "rdetr_msda_forward_opt_bf16": [_vp, _c_int] + [_vp] * 4 + [_c_int] * 8 + [_vp, _vp, _vp],
-    "rdetr_msda_forward_fused_opt_bf16": [_vp, _c_int, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 8 + [_vp, _vp, _vp],
+    "rdetr_msda_forward_opt_bf16": [_vp, _c_int] + [_vp] * 4 + [_c_int] * 8 + [_vp, _vp],
+    "rdetr_msda_forward_fused_opt_bf16": [_vp, _c_int, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 8 + [_vp, _vp],
     "rdetr_value_to_head_major_bf16": [_vp, _c_ll, _vp] + [_c_int] * 4 + [_vp, _vp],
     "rdetr_msda_backward_f32": [_vp] * 6 + [_c_int] * 7 + [_vp] * 4,
     "rdetr_relation_bias_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp],
@@ -81,8 +81,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.argtypes = argtypes
         fn.restype = ctypes.c_char_p if name == "rdetr_status_string" else (_c_ll if name == "rdetr_topk_workspace_bytes" else _c_int)
-    if lib.rdetr_abi_version() != 3:
-        raise RdetrError(f"ABI version mismatch: library {lib.rdetr_abi_version()}, binding 3")
+    if lib.rdetr_abi_version() != 2:
+        raise RdetrError(f"ABI version mismatch: library {lib.rdetr_abi_version()}, binding 2")
     _lib = lib
     return lib
 

@@ -34,7 +34,6 @@ constexpr int kHeadDim = 32;
 constexpr int kPoints = 4;
 constexpr int kMaxLevels = 8;
 constexpr int kWavesPerBlock = 4;
-constexpr int kMmAhead = 2;                       // points whose gathers are in flight ahead of the one being summed (bf16 kernel)
 constexpr unsigned kInvalidOffset = 0x80000000u;   // >= num_records for every supported tensor
 
 struct LevelTable {
@@ -109,6 +108,48 @@ template <int WIDTH> __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
+// N consecutive query-side values with one load (16-byte alignment for 16 bytes and more, natural alignment below)
+template <typename Q, int N> struct LoadQ;
+template <> struct LoadQ<float, 2> {
+    static __device__ __forceinline__ void run(const float *p, float (&v)[2])
+    {
+        const f32x2 r = *reinterpret_cast<const f32x2 *>(p);
+        v[0] = r.x; v[1] = r.y;
+    }
+};
+template <> struct LoadQ<float, 4> {
+    static __device__ __forceinline__ void run(const float *p, float (&v)[4])
+    {
+        const f32x4 r = *reinterpret_cast<const f32x4 *>(p);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+};
+template <> struct LoadQ<float, 8> {
+    static __device__ __forceinline__ void run(const float *p, float (&v)[8])
+    {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+template <> struct LoadQ<uint16_t, 4> {
+    static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[4])
+    {
+        const u32x2 r = *reinterpret_cast<const u32x2 *>(p);
+        v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    }
+};
+template <> struct LoadQ<uint16_t, 8> {
+    static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[8])
+    {
+        const u32x4 r = *reinterpret_cast<const u32x4 *>(p);
+        v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+        v[4] = __builtin_bit_cast(float, r.z << 16); v[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
+        v[6] = __builtin_bit_cast(float, r.w << 16); v[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
+    }
+};
+
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -120,11 +161,12 @@ __device__ __forceinline__ void split2_bf16(float a, float b, unsigned &hi, unsi
     lo = __builtin_bit_cast(unsigned, bf16x2_t{(__bf16)ra, (__bf16)rb});
 }
 
-// One sampling point of 16 queries x 4 lanes on the matrix cores: v_mfma_f32_4x4x4_16b_bf16 is 16 independent 4x4x4 products, one
-// per query (lanes 4q .. 4q+3).  K = the 4 corners.  B[k][j] = corner k of channel c of lane j: the lane's four 16-byte loads
-// re-paired by v_perm_b32 (2 per channel pair and corner pair) -- no bf16 -> fp32 unpacking.  A[i][k] = the corner weights, row 0
-// their bf16 high parts, row 1 the low parts (rows 2, 3 repeat them), so D[0][j] + D[1][j] is the fp32-weighted sum of lane j's
-// channel c up to 2^-17 per weight; products are exact, accumulation fp32.  r00..r11: the loads; wq: this lane's A row.
+// One sampling point of 16 queries x 4 lanes on the matrix cores (bf16 value): v_mfma_f32_4x4x4_16b_bf16 is 16 independent
+// 4x4x4 products, one per query (lanes 4q .. 4q+3).  K = the 4 corners.  B[k][j] = corner k of channel c of lane j: the lane's
+// four 16-byte loads re-paired by v_perm_b32 (2 per channel pair and corner pair) -- no bf16 -> fp32 unpacking.  A[i][k] = the
+// corner weights, row 0 their bf16 high parts, row 1 the low parts (rows 2, 3 repeat them), so D[0][j] + D[1][j] is the
+// fp32-weighted sum of lane j's channel c up to 2^-17 per weight; products are exact, accumulation fp32.  Half the vector-ALU
+// instructions of unpack + v_pk_fma_f32 (20 vs 52 per point).  r00..r11: the loads; wq: this lane's A row.
 __device__ __forceinline__ void mfma_point(const u32x4 &r00, const u32x4 &r01, const u32x4 &r10, const u32x4 &r11, const u32x2 &wq,
                                            f32x4 (&acc)[8])
 {
@@ -140,16 +182,6 @@ __device__ __forceinline__ void mfma_point(const u32x4 &r00, const u32x4 &r01, c
     }
 }
 
-// 16 bytes of a bf16 head row from LDS (byte offset into the workgroup's dynamic LDS), unpacked like ValueIO<uint16_t>::load_run
-__device__ __forceinline__ void lds_run(const unsigned char *lds, unsigned off, float (&v)[8])
-{
-    const u32x4 r = *reinterpret_cast<const u32x4 *>(lds + off);
-    v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
-    v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
-    v[4] = __builtin_bit_cast(float, r.z << 16); v[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
-    v[6] = __builtin_bit_cast(float, r.w << 16); v[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
-}
-
 // LT = compile-time level count (4, 5) or 0 for a run-time L in [1, 8].
 // FUSED = false: `src_a` = sampling locations fp32 [B,Nq,H,L,P,2], `src_b` = soft-maxed weights fp32 [B,Nq,H,L,P]
 //                (the reference operator's inputs, ms_deform_attn_cuda.cu:12-19).
@@ -157,19 +189,23 @@ __device__ __forceinline__ void lds_run(const unsigned char *lds, unsigned off, 
 //                value's dtype, `ref` = reference points fp32 [B,Nq,L,ref_dim]; the softmax over L*P and
 //                loc = ref + off/(W,H)  |  ref_xy + off/P * ref_wh * 0.5  (ms_deform_attn.py:326-349) happen in the
 //                set-up phase, so neither locations nor weights ever exist in HBM.
-// MM (bf16 only) = the weighted sum on the matrix cores (mfma_point) instead of unpack + v_pk_fma_f32.
-template <typename T, int LT, bool FUSED, bool MM>
+template <typename T, int LT, bool FUSED>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
     int L_rt, int Nq, int tiles_per_image, int nblk, T *__restrict__ out,
-    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major, int patch2d)
+    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
     constexpr int kCh = IO::kRunCh;              // channels per lane (16 bytes)
     constexpr int kSlots = kWave / kSub;         // queries per wave (8 fp32, 16 bf16)
     constexpr int kPtsPerLane = LT ? (LT * kPoints + kSub - 1) / kSub : (kMaxLevels * kPoints) / kSub;
+    // LT == 4: a lane prepares kPtsPerLane CONSECUTIVE points (4 = one level for bf16, 2 for fp32), so that its share of the
+    // locations / weights (or raw offsets / logits / reference point) arrives with 3 vector loads instead of 8-12 narrow ones
+    // -- the kernel is bound by the number of vector-memory instructions.  Otherwise points sub, sub + kSub, ...
+    constexpr bool kConsec = LT == 4;
+    constexpr bool kMM = sizeof(T) == 2;         // bf16: the weighted sum on the matrix cores (mfma_point)
     const int L = LT ? LT : L_rt;
     const int LP = L * kPoints;
 
@@ -194,26 +230,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int qs = lane / kSub, sub = lane % kSub;
-    int q = (tile * kWavesPerBlock + wave) * kSlots + qs;
-    bool qok = q < Nq;
-    if (patch2d) {
-        // the queries are the pyramid's own pixels (Nq == S): a workgroup takes a kSlots x 4 patch of one level -- one pixel row
-        // per wave -- instead of 4 * kSlots consecutive pixels, so that the footprints of its waves overlap in L1.  Any order of
-        // the queries gives the same result; the host counted the patches (tiles_per_image) from its copy of the shapes.
-        int t = tile, l = 0, nx = (lvl.w[0] + kSlots - 1) / kSlots;
-        for (;;) {
-            const int n = nx * ((lvl.h[l] + kWavesPerBlock - 1) / kWavesPerBlock);
-            if (t < n || l == L - 1) break;
-            t -= n;
-            ++l;
-            nx = (lvl.w[l] + kSlots - 1) / kSlots;
-        }
-        const int ty = t / nx, tx = t - ty * nx;
-        const int y = ty * kWavesPerBlock + wave, x = tx * kSlots + qs;
-        qok = y < lvl.h[l] && x < lvl.w[l];
-        q = lvl.start[l] + y * lvl.w[l] + x;
-        qok = qok && q < Nq;
-    }
+    const int q = (tile * kWavesPerBlock + wave) * kSlots + qs;
+    const bool qok = q < Nq;
 
     // value [B,S,H,D] (the reference operator's layout: a pixel's heads side by side) or, head_major, [B,H,S,D]: either way
     // the (image, head) plane sits behind one wave-uniform buffer descriptor and a pixel step is `pixb` bytes
@@ -230,7 +248,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const size_t row = (size_t)b * Nq + (qok ? q : 0);
     const size_t hrow = (row * kHeads + m) * (size_t)LP;
 
-    // ---- set-up: lane (qs, sub) prepares points sub, sub+kSub, ... of query qs ---------------------
+    // ---- set-up: lane (qs, sub) prepares points sub, sub+kSub, ... (kConsec: sub*kPtsPerLane, +1, ...) of query qs -------
+    auto point_of = [&](int k) { return kConsec ? sub * kPtsPerLane + k : sub + k * kSub; };
     float pa[kPtsPerLane];
     f32x2 pxy[kPtsPerLane];
     if constexpr (FUSED) {
@@ -238,13 +257,24 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
         const T *off_q = static_cast<const T *>(src_a) + (ld_a ? row * (size_t)ld_a + (size_t)m * LP * 2 : hrow * 2);
         const T *lg_q = static_cast<const T *>(src_b) + (ld_b ? row * (size_t)ld_b + (size_t)m * LP : hrow);
         float mx = -__builtin_inff();
+        if constexpr (kConsec) {
+            float o2[2 * kPtsPerLane];
+            LoadQ<T, 2 * kPtsPerLane>::run(off_q + 2 * point_of(0), o2);
+            LoadQ<T, kPtsPerLane>::run(lg_q + point_of(0), pa);
 #pragma unroll
-        for (int k = 0; k < kPtsPerLane; ++k) {
-            const int pt = sub + k * kSub;
-            const bool ok = pt < LP;
-            pa[k] = ok ? load_q<T>(lg_q + pt) : -__builtin_inff();
-            pxy[k] = ok ? load_q2<T>(off_q + 2 * pt) : f32x2{0.f, 0.f};
-            mx = fmaxf(mx, pa[k]);
+            for (int k = 0; k < kPtsPerLane; ++k) {
+                pxy[k] = f32x2{o2[2 * k], o2[2 * k + 1]};
+                mx = fmaxf(mx, pa[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPtsPerLane; ++k) {
+                const int pt = point_of(k);
+                const bool ok = pt < LP;
+                pa[k] = ok ? load_q<T>(lg_q + pt) : -__builtin_inff();
+                pxy[k] = ok ? load_q2<T>(off_q + 2 * pt) : f32x2{0.f, 0.f};
+                mx = fmaxf(mx, pa[k]);
+            }
         }
         mx = group_max<kSub>(mx);
         float sum = 0.f;
@@ -254,34 +284,55 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             sum += pa[k];
         }
         sum = group_sum<kSub>(sum);
+        f32x4 rc = {0.f, 0.f, 0.f, 0.f};          // kConsec: the lane's points share a level -> one reference point
+        if constexpr (kConsec) {
+            const float *rp = ref + (row * L + point_of(0) / kPoints) * (size_t)ref_dim;
+            if (ref_dim == 2) {
+                const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
+                rc = f32x4{r2.x, r2.y, 0.f, 0.f};
+            } else {
+                rc = *reinterpret_cast<const f32x4 *>(rp);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kPtsPerLane; ++k) {
-            const int pt = sub + k * kSub;
+            const int pt = point_of(k);
             const int l = (pt < LP ? pt : 0) / kPoints;
-            const float *rp = ref + (row * L + l) * (size_t)ref_dim;
+            if constexpr (!kConsec) {
+                const float *rp = ref + (row * L + l) * (size_t)ref_dim;
+                rc = ref_dim == 2 ? f32x4{rp[0], rp[1], 0.f, 0.f} : f32x4{rp[0], rp[1], rp[2], rp[3]};
+            }
             pa[k] = pa[k] / sum;
             if (ref_dim == 2) {
-                pxy[k].x = rp[0] + pxy[k].x / (float)lvl.w[l];
-                pxy[k].y = rp[1] + pxy[k].y / (float)lvl.h[l];
+                pxy[k].x = rc.x + pxy[k].x / (float)lvl.w[l];
+                pxy[k].y = rc.y + pxy[k].y / (float)lvl.h[l];
             } else {
-                pxy[k].x = rp[0] + pxy[k].x * (1.0f / kPoints) * rp[2] * 0.5f;
-                pxy[k].y = rp[1] + pxy[k].y * (1.0f / kPoints) * rp[3] * 0.5f;
+                pxy[k].x = rc.x + pxy[k].x * (1.0f / kPoints) * rc.z * 0.5f;
+                pxy[k].y = rc.y + pxy[k].y * (1.0f / kPoints) * rc.w * 0.5f;
             }
         }
     } else {
         const float *loc_q = static_cast<const float *>(src_a) + hrow * 2;
         const float *att_q = static_cast<const float *>(src_b) + hrow;
+        if constexpr (kConsec) {
+            float l2[2 * kPtsPerLane];
+            LoadQ<float, 2 * kPtsPerLane>::run(loc_q + 2 * point_of(0), l2);
+            LoadQ<float, kPtsPerLane>::run(att_q + point_of(0), pa);
 #pragma unroll
-        for (int k = 0; k < kPtsPerLane; ++k) {
-            const int pt = sub + k * kSub;
-            const bool ok = pt < LP;
-            pxy[k] = ok ? *reinterpret_cast<const f32x2 *>(loc_q + 2 * pt) : f32x2{0.f, 0.f};
-            pa[k] = ok ? att_q[pt] : 0.f;
+            for (int k = 0; k < kPtsPerLane; ++k) pxy[k] = f32x2{l2[2 * k], l2[2 * k + 1]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPtsPerLane; ++k) {
+                const int pt = point_of(k);
+                const bool ok = pt < LP;
+                pxy[k] = ok ? *reinterpret_cast<const f32x2 *>(loc_q + 2 * pt) : f32x2{0.f, 0.f};
+                pa[k] = ok ? att_q[pt] : 0.f;
+            }
         }
     }
 #pragma unroll
     for (int k = 0; k < kPtsPerLane; ++k) {
-        const int pt = sub + k * kSub;
+        const int pt = point_of(k);
         if (pt < LP) {
             const f32x2 xy = pxy[k];
             const float a = pa[k];
@@ -315,8 +366,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             wt.z = inside ? ly * hx * a : 0.f;
             wt.w = inside ? ly * lx * a : 0.f;
             soff[pt * kSlots + qs] = o;
-            if constexpr (MM) {
-                unsigned h01, l01, h23, l23;                // {hi(00,01), hi(10,11), lo(00,01), lo(10,11)}: A rows 0 and 1
+            if constexpr (kMM) {
+                unsigned h01, l01, h23, l23;                // {hi(00,01), hi(10,11), lo(00,01), lo(10,11)}: A rows 0 and 1 of mfma_point
                 split2_bf16(wt.x, wt.y, h01, l01);
                 split2_bf16(wt.z, wt.w, h23, l23);
                 swgt[pt * kSlots + qs] = __builtin_bit_cast(f32x4, u32x4{h01, h23, l01, l23});
@@ -331,46 +382,20 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    if constexpr (MM) {
-        static_assert(!MM || sizeof(T) == 2, "the MFMA form is the bf16 kernel's");
+    if constexpr (kMM) {
         f32x4 accm[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) accm[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned wsel = (unsigned)(sub & 1) * 8u;
-        struct PointRegs {
-            u32x4 r00, r01, r10, r11;
-            u32x2 wq;
-        };
-        auto issue = [&](int pt, PointRegs &p) {
-            const u32x4 o = soff[pt * kSlots + qs];
-            p.wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + pt * kSlots + qs) + wsel);
-            p.r00 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + lane_off, 0, 0);
-            p.r01 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + lane_off, 0, 0);
-            p.r10 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + lane_off, 0, 0);
-            p.r11 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + lane_off, 0, 0);
-        };
-        if constexpr (LT > 0) {
-            // software pipeline: the loads of point pt + kMmAhead are issued before point pt is consumed (the scheduler, left
-            // alone, issues four loads and waits for them); (kMmAhead + 1) x 4 loads of 1 KiB per wave in flight
-            constexpr int LPc = LT * kPoints;
-            PointRegs ring[kMmAhead + 1];
-#pragma unroll
-            for (int pt = 0; pt < kMmAhead; ++pt) issue(pt, ring[pt]);
-#pragma unroll
-            for (int pt = 0; pt < LPc; ++pt) {
-                if (pt + kMmAhead < LPc) issue(pt + kMmAhead, ring[(pt + kMmAhead) % (kMmAhead + 1)]);
-                __builtin_amdgcn_sched_barrier(0);
-                const PointRegs &p = ring[pt % (kMmAhead + 1)];
-                mfma_point(p.r00, p.r01, p.r10, p.r11, p.wq, accm);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
 #pragma unroll 2
-            for (int pt = 0; pt < LP; ++pt) {
-                PointRegs p;
-                issue(pt, p);
-                mfma_point(p.r00, p.r01, p.r10, p.r11, p.wq, accm);
-            }
+        for (int pt = 0; pt < LP; ++pt) {        // 8 loads of 16 B in flight per lane
+            const u32x4 o = soff[pt * kSlots + qs];
+            const u32x2 wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + pt * kSlots + qs) + wsel);
+            const u32x4 r00 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + lane_off, 0, 0);
+            const u32x4 r01 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + lane_off, 0, 0);
+            const u32x4 r10 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + lane_off, 0, 0);
+            const u32x4 r11 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + lane_off, 0, 0);
+            mfma_point(r00, r01, r10, r11, wq, accm);
         }
         float res[kCh];
 #pragma unroll
@@ -381,7 +406,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     float acc[kCh];
 #pragma unroll
     for (int c = 0; c < kCh; ++c) acc[c] = 0.f;
-    constexpr int kUnroll = 16 / kCh;            // 16 loads in flight per lane for fp32, 8 (x 16 B) for bf16
+    constexpr int kUnroll = 16 / kCh;            // 16 loads in flight per lane for fp32
 #pragma unroll kUnroll
     for (int pt = 0; pt < LP; ++pt) {
         const u32x4 o = soff[pt * kSlots + qs];
@@ -402,258 +427,6 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
         }
     }
     if (qok) IO::store_run(out + row * (kHeads * kHeadDim) + m * kHeadDim + sub * kCh, acc);
-}
-
-// ---------------------------------------------------------------------------------------------
-// "Coarse planes in LDS" variant of the query-run kernel: bf16, head-major value, L == 4.
-//
-// The query-run kernel is bound by the texture path: every gather instruction moves 64 lanes x 16 B at 64 B per clock and CU,
-// whatever it hits, and the lines it misses are filled through the same L1.  Half of the samples of the 4-level operator land
-// on levels 2 and 3, whose head-major planes are small (800 x 1333 input: 1,050 + 273 pixels x 64 B = 85 KB per (image, head)).
-// Here a persistent 8-wave workgroup owns one (image, head) and a slice of its query runs, copies those two planes into LDS
-// once, and gathers levels 2 / 3 with ds_read_b128 (zero padding = the offset of a 64-byte row of zeros behind the planes)
-// while levels 0 / 1 keep the range-checked buffer loads.  Few, fat waves (2 per SIMD, 256 registers each) instead of many
-// thin ones: a wave issues all 32 gathers of levels 0 / 1 at once, sums levels 2 / 3 out of LDS while they fly, and has the
-// next run's inputs on the way before it starts on the current one.  Mapping and per-corner arithmetic are the query-run
-// kernel's (mfma_point); the order of summation over the points differs (levels 2, 3, then 0, 1).
-constexpr int kCoWaves = 8;
-constexpr int kCoSlots = 16;                       // queries per wave
-constexpr int kCoPts = 4 * kPoints;                // points of a (query, head): L == 4
-constexpr int kCoFine = 2 * kPoints;               // points of levels 0 / 1
-constexpr int kCoStageBytes = kCoWaves * kCoPts * kCoSlots * 32;           // 64 KiB
-constexpr int kCoMaxPlaneBytes = 92 * 1024;        // levels 2 + 3 of one head; 64 KiB + 92 KiB + zeros + table < 160 KiB
-
-template <bool FUSED>
-__global__ __launch_bounds__(kCoWaves *kWave) void msda_fwd_coarse_lds_kernel(
-    const uint16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
-    const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S, int Nq,
-    int splits, int nblk, uint16_t *__restrict__ out, const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b)
-{
-    using T = uint16_t;
-    using IO = ValueIO<T>;
-    constexpr int L = 4, LP = L * kPoints;
-    extern __shared__ __attribute__((aligned(16))) unsigned char co_lds[];
-    __shared__ LevelTable lvl;
-
-    const int tid = threadIdx.x;
-    if (tid < L) {
-        lvl.h[tid] = (int)shapes[2 * tid];
-        lvl.w[tid] = (int)shapes[2 * tid + 1];
-        lvl.start[tid] = (int)level_start[tid];
-    }
-    __syncthreads();
-
-    const int logical = xcd_contiguous_block(blockIdx.x, nblk);
-    const int bm = logical / splits, split = logical - bm * splits;
-    const int b = bm / kHeads, m = bm - b * kHeads;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int qs = lane >> 2, sub = lane & 3;
-
-    // ---- levels 2, 3 of this (image, head): global -> LDS, once -------------------------------------
-    // (a pyramid whose levels 2 + 3 exceed the LDS budget -- or whose level table is not ascending -- keeps every level on
-    // the buffer loads: same results, no LDS planes)
-    const int coarse0 = lvl.start[2];
-    const bool in_lds = coarse0 >= 0 && coarse0 <= S && (long long)(S - coarse0) * IO::kHeadBytes <= kCoMaxPlaneBytes &&
-                        lvl.start[3] >= coarse0;
-    const unsigned plane_bytes = in_lds ? (unsigned)(S - coarse0) * IO::kHeadBytes : 0u;
-    const T *plane = value + ((size_t)b * kHeads + m) * (size_t)S * kHeadDim;
-    u32x4 *planes = reinterpret_cast<u32x4 *>(co_lds + kCoStageBytes);
-    {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(plane + (size_t)(in_lds ? coarse0 : 0) * kHeadDim);
-        const int n16 = (int)(plane_bytes / 16);
-        for (int i = tid; i < n16; i += kCoWaves * kWave) planes[i] = src[i];
-        if (tid < 4) planes[n16 + tid] = u32x4{0u, 0u, 0u, 0u};
-    }
-    __syncthreads();
-    const unsigned zero_row = (unsigned)kCoStageBytes + plane_bytes;       // LDS byte offset of the row of zeros
-
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(plane), 0, (unsigned)S * IO::kHeadBytes, 0x00020000);
-    const unsigned lane_off = (unsigned)sub * 16u;
-    const unsigned wsel = (unsigned)(sub & 1) * 8u;
-    u32x4 *soff = reinterpret_cast<u32x4 *>(co_lds + wave * (kCoPts * kCoSlots * 32));
-    f32x4 *swgt = reinterpret_cast<f32x4 *>(co_lds + wave * (kCoPts * kCoSlots * 32) + kCoPts * kCoSlots * 16);
-
-    // what lane (qs, sub) reads for its query: point `sub` of every level k (point index sub + 4 k)
-    struct Inputs {
-        float pa[L];                   // FUSED: raw logits, else the weights
-        f32x2 pxy[L];                  // FUSED: raw offsets, else the locations
-        f32x4 rp[L];                   // FUSED: reference point of level k (xy | xywh)
-    };
-    auto load_inputs = [&](int run) {
-        Inputs in;
-        const int q = run * kCoSlots + qs;
-        const size_t row = (size_t)b * Nq + (q < Nq ? q : 0);
-        const size_t hrow = (row * kHeads + m) * (size_t)LP;
-        if constexpr (FUSED) {
-            const T *off_q = static_cast<const T *>(src_a) + (ld_a ? row * (size_t)ld_a + (size_t)m * LP * 2 : hrow * 2);
-            const T *lg_q = static_cast<const T *>(src_b) + (ld_b ? row * (size_t)ld_b + (size_t)m * LP : hrow);
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const int pt = sub + k * kPoints;
-                in.pa[k] = load_q<T>(lg_q + pt);
-                in.pxy[k] = load_q2<T>(off_q + 2 * pt);
-                const float *rp = ref + (row * L + k) * (size_t)ref_dim;
-                if (ref_dim == 2) {
-                    const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
-                    in.rp[k] = f32x4{r2.x, r2.y, 0.f, 0.f};
-                } else {
-                    in.rp[k] = *reinterpret_cast<const f32x4 *>(rp);
-                }
-            }
-        } else {
-            const float *loc_q = static_cast<const float *>(src_a) + hrow * 2;
-            const float *att_q = static_cast<const float *>(src_b) + hrow;
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const int pt = sub + k * kPoints;
-                in.pxy[k] = *reinterpret_cast<const f32x2 *>(loc_q + 2 * pt);
-                in.pa[k] = att_q[pt];
-                in.rp[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        return in;
-    };
-
-    struct PointRegs {
-        u32x4 r00, r01, r10, r11;
-        u32x2 wq;
-    };
-    auto issue_global = [&](int pt, PointRegs &p) {
-        const u32x4 o = soff[pt * kCoSlots + qs];
-        p.wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + pt * kCoSlots + qs) + wsel);
-        p.r00 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + lane_off, 0, 0);
-        p.r01 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + lane_off, 0, 0);
-        p.r10 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + lane_off, 0, 0);
-        p.r11 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + lane_off, 0, 0);
-    };
-
-    const int nruns = (Nq + kCoSlots - 1) / kCoSlots;
-    const int run0 = (int)((long long)split * nruns / splits), run1 = (int)((long long)(split + 1) * nruns / splits);
-    int run = run0 + wave;
-    if (run >= run1) return;
-    Inputs next = load_inputs(run);
-    for (; run < run1; run += kCoWaves) {
-        Inputs in = next;
-        if (run + kCoWaves < run1) next = load_inputs(run + kCoWaves);      // on its way while this run is gathered
-        __builtin_amdgcn_sched_barrier(0);
-        const int q = run * kCoSlots + qs;
-        const bool qok = q < Nq;
-        const size_t row = (size_t)b * Nq + (qok ? q : 0);
-
-        if constexpr (FUSED) {
-            float mx = fmaxf(fmaxf(in.pa[0], in.pa[1]), fmaxf(in.pa[2], in.pa[3]));
-            mx = group_max<4>(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                in.pa[k] = expf(in.pa[k] - mx);
-                sum += in.pa[k];
-            }
-            sum = group_sum<4>(sum);
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                in.pa[k] = in.pa[k] / sum;
-                if (ref_dim == 2) {
-                    in.pxy[k].x = in.rp[k].x + in.pxy[k].x / (float)lvl.w[k];
-                    in.pxy[k].y = in.rp[k].y + in.pxy[k].y / (float)lvl.h[k];
-                } else {
-                    in.pxy[k].x = in.rp[k].x + in.pxy[k].x * (1.0f / kPoints) * in.rp[k].z * 0.5f;
-                    in.pxy[k].y = in.rp[k].y + in.pxy[k].y * (1.0f / kPoints) * in.rp[k].w * 0.5f;
-                }
-            }
-        }
-
-        // ---- set-up of the 16 points: corner offsets (levels 0 / 1: bytes in the plane, levels 2 / 3: LDS bytes) and weights
-#pragma unroll
-        for (int k = 0; k < L; ++k) {
-            const f32x2 xy = in.pxy[k];
-            const float a = in.pa[k];
-            const int h = lvl.h[k], w = lvl.w[k];
-            const float x = xy.x * (float)w - 0.5f;
-            const float y = xy.y * (float)h - 0.5f;
-            const bool inside = qok && (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);   // false for NaN
-            const float xf = floorf(x), yf = floorf(y);
-            const int x0 = inside ? (int)xf : 0, y0 = inside ? (int)yf : 0;
-            const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
-            const bool okx0 = inside && x0 >= 0, okx1 = inside && x0 + 1 <= w - 1;
-            const bool oky0 = y0 >= 0, oky1 = y0 + 1 <= h - 1;
-            const int pix = lvl.start[k] + y0 * w + x0;
-            const bool lds_level = k >= 2 && in_lds;
-            const unsigned none = lds_level ? zero_row : kInvalidOffset;
-            const unsigned base = lds_level ? (unsigned)(pix - coarse0) * IO::kHeadBytes + (unsigned)kCoStageBytes
-                                            : (unsigned)pix * IO::kHeadBytes;
-            const unsigned rowb = (unsigned)w * IO::kHeadBytes;
-            u32x4 o;
-            o.x = (okx0 && oky0) ? base : none;
-            o.y = (okx1 && oky0) ? base + IO::kHeadBytes : none;
-            o.z = (okx0 && oky1) ? base + rowb : none;
-            o.w = (okx1 && oky1) ? base + rowb + IO::kHeadBytes : none;
-            if (pad_mask) {
-                const unsigned char *mp = pad_mask + (size_t)b * S + pix;
-                if (okx0 && oky0 && mp[0]) o.x = none;
-                if (okx1 && oky0 && mp[1]) o.y = none;
-                if (okx0 && oky1 && mp[w]) o.z = none;
-                if (okx1 && oky1 && mp[w + 1]) o.w = none;
-            }
-            const float w00 = inside ? hy * hx * a : 0.f, w01 = inside ? hy * lx * a : 0.f;
-            const float w10 = inside ? ly * hx * a : 0.f, w11 = inside ? ly * lx * a : 0.f;
-            unsigned h01, l01, h23, l23;                // A rows 0 (bf16 high parts) and 1 (low parts) of mfma_point
-            split2_bf16(w00, w01, h01, l01);
-            split2_bf16(w10, w11, h23, l23);
-            soff[(k * kPoints + sub) * kCoSlots + qs] = o;
-            swgt[(k * kPoints + sub) * kCoSlots + qs] = __builtin_bit_cast(f32x4, u32x4{h01, h23, l01, l23});
-        }
-        // staging is private to the wave and LDS operations of one wave complete in order
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        f32x4 accm[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) accm[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        PointRegs ring[kCoFine];
-#pragma unroll
-        for (int pt = 0; pt < kCoFine; ++pt) issue_global(pt, ring[pt]);     // levels 0 / 1: 32 gathers in flight
-        __builtin_amdgcn_sched_barrier(0);
-        if (in_lds) {
-#pragma unroll 4
-            for (int pt = kCoFine; pt < kCoPts; ++pt) {                         // levels 2 / 3 out of LDS meanwhile
-                const u32x4 o = soff[pt * kCoSlots + qs];
-                const u32x2 wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + pt * kCoSlots + qs) + wsel);
-                const u32x4 r00 = *reinterpret_cast<const u32x4 *>(co_lds + o.x + lane_off);
-                const u32x4 r01 = *reinterpret_cast<const u32x4 *>(co_lds + o.y + lane_off);
-                const u32x4 r10 = *reinterpret_cast<const u32x4 *>(co_lds + o.z + lane_off);
-                const u32x4 r11 = *reinterpret_cast<const u32x4 *>(co_lds + o.w + lane_off);
-                mfma_point(r00, r01, r10, r11, wq, accm);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int pt = 0; pt < kCoFine; ++pt) {
-            mfma_point(ring[pt].r00, ring[pt].r01, ring[pt].r10, ring[pt].r11, ring[pt].wq, accm);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!in_lds) {                                                          // planes too large: levels 2 / 3 the same way
-#pragma unroll
-            for (int pt = 0; pt < kCoFine; ++pt) issue_global(kCoFine + pt, ring[pt]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int pt = 0; pt < kCoFine; ++pt) {
-                mfma_point(ring[pt].r00, ring[pt].r01, ring[pt].r10, ring[pt].r11, ring[pt].wq, accm);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        float res[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) res[c] = accm[c].x + accm[c].y;
-        if (qok) IO::store_run(out + row * (kHeads * kHeadDim) + m * kHeadDim + sub * 8, res);
-        // the next run's set-up overwrites the staging: its reads above are done (same wave, LDS in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -706,19 +479,6 @@ __global__ __launch_bounds__(256) void msda_fwd_generic_kernel(
     }
 }
 
-constexpr int kCoMinQueries = 8192;
-
-static int compute_units()
-{
-    static const int n = [] {
-        int dev = 0, cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-            cu = 256;
-        return cu;
-    }();
-    return n;
-}
-
 static bool fast_path(int H, int D, int L, int P)
 {
     return H == kHeads && D == kHeadDim && P == kPoints && L >= 1 && L <= kMaxLevels;
@@ -730,21 +490,25 @@ int msda_win_forward(const uint16_t *value, const int64_t *shapes, const int64_t
                      const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, int ld_a, int ld_b,
                      uint16_t *out, hipStream_t stream);
 
-template <typename T, bool FUSED, bool MM>
+template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
                         int S, int L, int Nq, int tiles, int nblk, T *out, const unsigned char *pad_mask, int ld_a, int ld_b,
-                        int head_major, int patch2d)
+                        int head_major)
 {
-    if (L == 4)
-        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED, MM>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, patch2d);
+    // the 4-level kernel reads a lane's share of the query-side inputs as 16-byte vectors
+    const bool vec_ok = reinterpret_cast<uintptr_t>(src_a) % 16 == 0 && reinterpret_cast<uintptr_t>(src_b) % 16 == 0 &&
+                        (!FUSED || (reinterpret_cast<uintptr_t>(ref) % 16 == 0 && (ld_a * (int)sizeof(T)) % 16 == 0 &&
+                                    (ld_b * (int)sizeof(T)) % 16 == 0));
+    if (L == 4 && vec_ok)
+        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
     else if (L == 5)
-        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED, MM>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, patch2d);
+        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
     else
-        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED, MM>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, patch2d);
+        hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
@@ -755,13 +519,11 @@ template <typename T, bool FUSED>
 static int msda_forward(const T *value, int layout, const int64_t *shapes, const int64_t *level_start, const void *src_a,
                         const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
                         int P, T *out, hipStream_t stream, int algo = RDETR_MSDA_AUTO, const unsigned char *pad_mask = nullptr,
-                        int ld_a = 0, int ld_b = 0, const int64_t *host_shapes = nullptr)
+                        int ld_a = 0, int ld_b = 0)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
     if (layout != RDETR_VALUE_BSHD && layout != RDETR_VALUE_BHSD) return RDETR_ERR_INVALID_ARG;
-    if (algo != RDETR_MSDA_AUTO && algo != RDETR_MSDA_DIRECT && algo != RDETR_MSDA_WINDOW && algo != RDETR_MSDA_COARSE_LDS &&
-        algo != RDETR_MSDA_DIRECT_FMA)
-        return RDETR_ERR_INVALID_ARG;
+    if (algo != RDETR_MSDA_AUTO && algo != RDETR_MSDA_DIRECT && algo != RDETR_MSDA_WINDOW) return RDETR_ERR_INVALID_ARG;
     if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
     if (B == 0 || Nq == 0) return RDETR_OK;
     if (!value || !shapes || !level_start || !src_a || !src_b || !out || (FUSED && !ref)) return RDETR_ERR_INVALID_ARG;
@@ -785,63 +547,16 @@ static int msda_forward(const T *value, int layout, const int64_t *shapes, const
             }
         }
         if (algo == RDETR_MSDA_WINDOW) return RDETR_ERR_UNSUPPORTED;
-        if constexpr (sizeof(T) == 2) {
-            // head-major, 4 levels, enough queries to keep a persistent workgroup per CU busy: levels 2 / 3 gathered from LDS
-            if (hm && L == 4 && (algo == RDETR_MSDA_COARSE_LDS || (algo == RDETR_MSDA_AUTO && Nq >= kCoMinQueries))) {
-                using Kern = void (*)(const uint16_t *, const int64_t *, const int64_t *, const void *, const void *, const float *,
-                                      int, int, int, int, int, uint16_t *, const unsigned char *, int, int);
-                const Kern kern = msda_fwd_coarse_lds_kernel<FUSED>;
-                constexpr int kLds = kCoStageBytes + kCoMaxPlaneBytes + 64;
-                static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-                if (attr != hipSuccess) return RDETR_ERR_LAUNCH;
-                const int cus = compute_units();
-                const long long pairs = (long long)B * H;
-                const int nruns = (Nq + kCoSlots - 1) / kCoSlots;
-                int splits = (int)(cus / pairs > 1 ? cus / pairs : 1);          // <= one workgroup per CU (150 KB of LDS each)
-                if (splits > nruns) splits = nruns;
-                const long long nblk = pairs * splits;
-                if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
-                hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kCoWaves * kWave), kLds, stream, value, shapes, level_start, src_a,
-                                   src_b, ref, ref_dim, S, Nq, splits, (int)nblk, out, pad_mask, ld_a, ld_b);
-                return launch_status();
-            }
-        }
-        if (algo == RDETR_MSDA_COARSE_LDS) return RDETR_ERR_UNSUPPORTED;
         const int slots = kWave / ValueIO<T>::kRunSub;                       // queries per wave (8 fp32 / 16 bf16)
         const int qpb = kWavesPerBlock * slots;
-        long long tiles = (Nq + qpb - 1) / qpb;
-        int patch2d = 0;
-        if (host_shapes && Nq == S) {
-            // encoder shape and the caller handed over a host copy of the level shapes: slots x 4 patches per level
-            long long n = 0, px = 0;
-            for (int l = 0; l < L; ++l) {
-                const long long h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
-                if (h <= 0 || w <= 0) { n = -1; break; }
-                n += ((w + slots - 1) / slots) * ((h + kWavesPerBlock - 1) / kWavesPerBlock);
-                px += h * w;
-            }
-            if (n > 0 && px == S) {
-                tiles = n;
-                patch2d = 1;
-            }
-        }
+        const long long tiles = (Nq + qpb - 1) / qpb;
         const long long nblk = (long long)B * H * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
-        if constexpr (sizeof(T) == 2) {
-            if (algo != RDETR_MSDA_DIRECT_FMA) {
-                launch_qrun<T, FUSED, true>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
-                                            src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, out, pad_mask, ld_a, ld_b,
-                                            hm ? 1 : 0, patch2d);
-                return launch_status();
-            }
-        }
-        launch_qrun<T, FUSED, false>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
-                                     src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, out, pad_mask, ld_a, ld_b, hm ? 1 : 0,
-                                     patch2d);
+        launch_qrun<T, FUSED>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
+                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, out, pad_mask, ld_a, ld_b, hm ? 1 : 0);
         return launch_status();
     }
-    if (FUSED || pad_mask || ld_a || ld_b || hm || algo == RDETR_MSDA_WINDOW || algo == RDETR_MSDA_COARSE_LDS || algo == RDETR_MSDA_DIRECT_FMA)
+    if (FUSED || pad_mask || ld_a || ld_b || hm || algo == RDETR_MSDA_WINDOW)
         return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
     const long long total = (long long)B * Nq * H * D;
     const long long want = (total + 255) / 256;
@@ -962,27 +677,26 @@ extern "C" int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int
 extern "C" int rdetr_msda_forward_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
                                            const int64_t *level_start_index, const float *sampling_loc,
                                            const float *attn_weight, int B, int S, int H, int D, int L, int Nq, int P,
-                                           int algo, const int64_t *spatial_shapes_host, uint16_t *out, void *stream)
+                                           int algo, uint16_t *out, void *stream)
 {
     return rdetr::msda_forward<uint16_t, false>(value, value_layout, spatial_shapes, level_start_index, sampling_loc,
                                                 attn_weight, nullptr, 0, B, S, H, D, L, Nq, P, out,
-                                                static_cast<hipStream_t>(stream), algo, nullptr, 0, 0, spatial_shapes_host);
+                                                static_cast<hipStream_t>(stream), algo);
 }
 
 extern "C" int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
                                                  const int64_t *level_start_index, const uint16_t *sampling_offsets,
                                                  int ld_offsets, const uint16_t *attn_logits, int ld_logits,
                                                  const float *reference_points, int ref_dim, const uint8_t *key_padding_mask,
-                                                 int B, int S, int H, int D, int L, int Nq, int P, int algo,
-                                                 const int64_t *spatial_shapes_host, uint16_t *out, void *stream)
+                                                 int B, int S, int H, int D, int L, int Nq, int P, int algo, uint16_t *out,
+                                                 void *stream)
 {
     if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
         ld_offsets % 2 != 0)
         return RDETR_ERR_INVALID_ARG;
     return rdetr::msda_forward<uint16_t, true>(value, value_layout, spatial_shapes, level_start_index, sampling_offsets,
                                                attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
-                                               static_cast<hipStream_t>(stream), algo, key_padding_mask, ld_offsets, ld_logits,
-                                               spatial_shapes_host);
+                                               static_cast<hipStream_t>(stream), algo, key_padding_mask, ld_offsets, ld_logits);
 }
 
 extern "C" int rdetr_value_to_head_major_bf16(const uint16_t *src, long long ld, const uint8_t *key_padding_mask, int B, int S,

@@ -177,8 +177,7 @@ class MultiScaleDeformableAttention(nn.Module):
             else:
                 vh = ops.value_to_head_major(v.view(v.shape[0], v.shape[1], -1), key_padding_mask)
             core = ops.ms_deform_attn_forward_fused(vh, spatial_shapes, level_start_index, offsets, logits,
-                                                    reference_points.float().contiguous(), None, value_layout="bhsd",
-                                                    algo=os.environ.get("RDETR_MSDA_ALGO", "auto"))
+                                                    reference_points.float().contiguous(), None, value_layout="bhsd")
         elif fused:
             # inference: softmax + location arithmetic happen inside the gather kernel's set-up phase, and so does the
             # padding mask (rows of padded positions count as zero: no fill pass over the projected value)

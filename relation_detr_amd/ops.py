@@ -9,8 +9,6 @@ No CPU path: a tensor that is not on a ROCm device raises, and so does a missing
 """
 from __future__ import annotations
 
-import ctypes
-import os
 import weakref
 from typing import Optional, Tuple
 
@@ -59,23 +57,6 @@ def host_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor) -
     return levels
 
 
-_host_shape_arrays: dict = {}
-
-
-def _host_shapes_ptr(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor):
-    """A host copy of `spatial_shapes` as an int64 C array (kept alive here; one per distinct pyramid) for the entry points that
-    take `spatial_shapes_host`: with it the encoder-shape launch orders its queries in 2-d patches."""
-    shapes, _ = host_levels(spatial_shapes, level_start_index)
-    arr = _host_shape_arrays.get(shapes)
-    if arr is None:
-        if len(_host_shape_arrays) > 64:
-            _host_shape_arrays.clear()
-        flat = [v for hw in shapes for v in hw]
-        arr = (ctypes.c_int64 * len(flat))(*flat)
-        _host_shape_arrays[shapes] = arr
-    return ctypes.cast(arr, ctypes.c_void_p)
-
-
 def check_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, num_value: int) -> None:
     """Host-side validation that the pyramid description matches the value tensor, so that the
     kernel's indexing assumptions hold before anything is launched."""
@@ -91,9 +72,8 @@ def check_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, 
 
 
 VALUE_BSHD, VALUE_BHSD = 0, 1                     # include/relation_detr_amd.h: RDETR_VALUE_*
-MSDA_AUTO, MSDA_DIRECT, MSDA_WINDOW, MSDA_COARSE_LDS = 0, 1, 2, 3     # RDETR_MSDA_*
-_PATCH2D = os.environ.get("RDETR_MSDA_PATCH2D", "1") != "0"      # A/B switch: hand the host copy of the shapes to the kernels
-_ALGO = {"auto": MSDA_AUTO, "direct": MSDA_DIRECT, "window": MSDA_WINDOW, "coarse_lds": MSDA_COARSE_LDS, "direct_fma": 4}
+MSDA_AUTO, MSDA_DIRECT, MSDA_WINDOW = 0, 1, 2     # RDETR_MSDA_*
+_ALGO = {"auto": MSDA_AUTO, "direct": MSDA_DIRECT, "window": MSDA_WINDOW}
 
 
 def _value_dims(value: torch.Tensor, layout: str):
@@ -112,7 +92,7 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
     """value [B,S,H,D] (fp32 or bf16), sampling_loc [B,Nq,H,L,P,2] fp32, attn_weight [B,Nq,H,L,P] fp32
     -> [B,Nq,H*D] in value's dtype.  ``im2col_step`` is accepted and ignored (no batch restriction).
     Not in the reference's signature (optional, bf16 only): ``value_layout="bhsd"`` for a head-major value [B,H,S,D]
-    (`value_to_head_major`), ``algo`` "auto" | "direct" | "window" | "coarse_lds" to name the kernel (tests, A/B timing)."""
+    (`value_to_head_major`), ``algo`` "auto" | "direct" | "window" to name the kernel (tests, A/B timing)."""
     _require_device(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                         sampling_loc=sampling_loc, attn_weight=attn_weight)
@@ -127,16 +107,15 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
     if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
         raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
     if algo not in _ALGO:
-        raise ValueError("algo must be 'auto', 'direct', 'direct_fma', 'window' or 'coarse_lds'")
+        raise ValueError("algo must be 'auto', 'direct' or 'window'")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
     if value.dtype == torch.bfloat16 and (value_layout != "bshd" or algo != "auto"):
         st = lib.rdetr_msda_forward_opt_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD,
                                              spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-                                             attn_weight.data_ptr(), B, S, H, D, L, Nq, P, _ALGO[algo],
-                                             _host_shapes_ptr(spatial_shapes, level_start_index) if _PATCH2D else None,
-                                             out.data_ptr(), _stream_ptr(value))
+                                             attn_weight.data_ptr(), B, S, H, D, L, Nq, P, _ALGO[algo], out.data_ptr(),
+                                             _stream_ptr(value))
         _lib.check(st, "rdetr_msda_forward_opt_bf16")
         return out
     if value_layout != "bshd" or algo != "auto":
@@ -227,7 +206,7 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
     if spatial_shapes.shape[0] != L:
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_offsets")
     if algo not in _ALGO:
-        raise ValueError("algo must be 'auto', 'direct', 'direct_fma', 'window' or 'coarse_lds'")
+        raise ValueError("algo must be 'auto', 'direct' or 'window'")
     if value.dtype not in (torch.float32, torch.bfloat16):
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
     if value.dtype == torch.float32 and (value_layout != "bshd" or algo != "auto"):
@@ -246,8 +225,7 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         st = lib.rdetr_msda_forward_fused_opt_bf16(
             value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), sampling_offsets.data_ptr(), ld_off, attn_logits.data_ptr(), ld_lg,
-            reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P, _ALGO[algo],
-            _host_shapes_ptr(spatial_shapes, level_start_index) if _PATCH2D else None, out.data_ptr(), _stream_ptr(value))
+            reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P, _ALGO[algo], out.data_ptr(), _stream_ptr(value))
         _lib.check(st, "rdetr_msda_forward_fused_opt_bf16")
         return out
     if ld_off or ld_lg or mask_ptr is not None:

@@ -169,62 +169,6 @@ def test_window_fused_producer(ops, ref_dim, strided):
     assert np.array_equal(auto, direct) or np.array_equal(auto, out)
 
 
-@pytest.mark.parametrize("shapes,B,nq,spread_px,scatter,poison", [
-    (R50, 2, None, 4.0, 0.02, True),                                         # BASELINE pyramid: levels 2 + 3 = 85 KB in LDS
-    ([(75, 61), (38, 31), (19, 16), (10, 8)], 3, None, 6.0, 0.3, True),      # small planes, ragged last run (Nq % 16 != 0)
-    ([(70, 70), (35, 35), (18, 18), (9, 9)], 1, 903, 2.0, 1.0, False),       # decoder-like: 903 scattered queries
-    ([(200, 304), (100, 152), (50, 76), (25, 38)], 1, 5000, 4.0, 0.5, False),    # levels 2 + 3 above the LDS budget: global gathers
-])
-def test_coarse_lds_kernel_matches_oracle_and_direct(ops, shapes, B, nq, spread_px, scatter, poison):
-    """algo = "coarse_lds" (head-major value, levels 2 / 3 gathered from LDS planes) against the C oracle and the direct kernel."""
-    from oracle import c_oracle
-    value, shp, start, loc, attn, S, L = _encoder_inputs(shapes, B, spread_px, seed=91 + B, scatter=scatter, poison=poison)
-    if nq is not None:
-        loc, attn = loc[:, :nq].contiguous(), attn[:, :nq].contiguous()
-    rest = (shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV))
-    vh = _head_major(value.to(DEV))
-    direct = ops.ms_deform_attn_forward(vh, *rest, value_layout="bhsd", algo="direct").float().cpu().numpy()
-    out = ops.ms_deform_attn_forward(vh, *rest, value_layout="bhsd", algo="coarse_lds").float().cpu().numpy()
-    # same per-corner arithmetic as the direct kernel, another order of summation over the points: one bf16 rounding apart
-    assert np.isfinite(out).all() and (np.abs(out - direct) <= 2.0 ** -7 * np.abs(direct) + 1e-3).all()
-    auto = ops.ms_deform_attn_forward(vh, *rest, value_layout="bhsd").float().cpu().numpy()
-    assert np.array_equal(auto, direct) or np.array_equal(auto, out)
-    if S * B <= 50000:
-        ref = c_oracle.msda_forward(value.float().numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
-        _check(out, ref, direct)
-    with pytest.raises(Exception):                                           # the operator's own layout: not this kernel
-        ops.ms_deform_attn_forward(value.to(DEV), *rest, algo="coarse_lds")
-
-
-@pytest.mark.parametrize("ref_dim,strided,masked", [(2, False, False), (4, False, True), (2, True, True)])
-def test_coarse_lds_fused_producer_and_padding_mask(ops, ref_dim, strided, masked):
-    """The fused-producer form (raw offsets / logits, strided, key_padding_mask inside the gather) on the LDS-plane kernel:
-    against the direct kernel (one bf16 rounding), which the tests above and test_gpu_parity pin to the oracle."""
-    shapes = [(96, 128), (48, 64), (24, 32), (12, 16)]
-    shp, start, S = pyramid(shapes)
-    g = torch.Generator().manual_seed(60 + ref_dim)
-    B, L = 2, 4
-    value = torch.randn(B, S, 8, 32, generator=g).to(torch.bfloat16).to(DEV)
-    off = (torch.randn(B, S, 8, L, 4, 2, generator=g) * 3).to(torch.bfloat16).to(DEV)
-    logits = (torch.randn(B, S, 8, L * 4, generator=g) * 2).to(torch.bfloat16).to(DEV)
-    ref = _pixel_refs(shapes)[None, :, None, :].expand(B, S, L, 2)
-    if ref_dim == 4:
-        ref = torch.cat([ref, torch.rand(B, S, L, 2, generator=g) * 0.2 + 0.02], -1)
-    ref = ref.contiguous().to(DEV)
-    if strided:
-        both = torch.cat([off.view(B, S, 256), logits.view(B, S, 128)], -1)
-        off, logits = both[..., :256].view(B, S, 8, L, 4, 2), both[..., 256:].view(B, S, 8, L * 4)
-    mask = (torch.rand(B, S, generator=g) < 0.2).to(DEV) if masked else None
-    args = (shp.to(DEV), start.to(DEV), off, logits, ref)
-    vh = _head_major(value)
-    direct = ops.ms_deform_attn_forward_fused(vh, *args, key_padding_mask=mask, value_layout="bhsd", algo="direct")
-    out = ops.ms_deform_attn_forward_fused(vh, *args, key_padding_mask=mask, value_layout="bhsd", algo="coarse_lds")
-    o, d = out.float(), direct.float()
-    assert torch.isfinite(o).all() and bool(((o - d).abs() <= 2.0 ** -7 * d.abs() + 1e-3).all())
-    auto = ops.ms_deform_attn_forward_fused(vh, *args, key_padding_mask=mask, value_layout="bhsd")
-    assert torch.equal(auto, direct) or torch.equal(auto, out)
-
-
 def test_window_unsupported_shapes(ops):
     from relation_detr_amd import _lib
     # five levels

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().rdetr_abi_version() == 3
+    assert _lib.load().rdetr_abi_version() == 2
     assert _lib.load().rdetr_status_string(-2).decode().startswith("shape not supported")
     assert _lib.load().rdetr_msda_fast_path(8, 32, 4, 4) == 1
     assert _lib.load().rdetr_msda_fast_path(8, 32, 5, 4) == 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process A/B of the bf16 MSDA kernels at the encoder shape of BASELINE.json configs[1]
-(B=4, S=Nq=22,323, 4 levels): "direct" (csrc/msda_fwd.hip), "window" (csrc/msda_win.hip) and "coarse" (levels 2 / 3 in LDS), value in the reference
+(B=4, S=Nq=22,323, 4 levels): "direct" (csrc/msda_fwd.hip) vs "window" (csrc/msda_win.hip), value in the reference
 operator's layout [B,S,H,D] ("bshd") and head-major [B,H,S,D] ("bhsd"), same inputs, interleaved rounds.
     python3 tools/ab_msda.py [reps] [rounds] [B]"""
 import os
@@ -40,18 +40,7 @@ def main():
         "direct bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="direct"),
         "window bshd": lambda: ops.ms_deform_attn_forward(value, shapes, start, loc, attn, algo="window"),
         "window bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="window"),
-        "dirfma bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="direct_fma"),
-        "coarse bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="coarse_lds"),
     }
-    def linear_order(algo):                     # the same kernels without the host copy of the shapes: queries in index order
-        def run():
-            ops._PATCH2D = False
-            try:
-                return ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo=algo)
-            finally:
-                ops._PATCH2D = True
-        return run
-    arms["dir 1d bhsd"] = linear_order("direct")
     outs = {k: f().float() for k, f in arms.items()}
     ref = outs["direct bshd"]
     for k, o in outs.items():

@@ -14,7 +14,12 @@
 //     (measured 12 % faster than a one-query-x-eight-heads mapping, which reads eight unrelated rows);
 //   * the per-(query, point) bilinear set-up (pixel coords, 4 corner byte offsets, 4 corner weights
 //     already multiplied by the attention weight) is computed ONCE by one lane and staged in LDS,
-//     then broadcast to the lanes of the row with two conflict-free ds_read_b128 per point;
+//     then broadcast to the lanes of the row with two LDS reads per point.  With 4 levels a lane prepares
+//     4 consecutive points (one level), so its locations / weights arrive with 3 vector loads: the kernel
+//     is bound by the NUMBER of vector-memory instructions (16 clocks each in the texture addresser);
+//   * bf16: the weighted sum runs on the matrix cores -- v_mfma_f32_4x4x4_16b_bf16 is 16 independent
+//     4x4x4 products, one per query; the four 16-byte loads of a lane are re-paired by v_perm_b32 into
+//     the B operand, the corner weights (bf16 high + low parts) are the A operand (mfma_point below);
 //   * corners outside the level get the byte offset 0x80000000: the buffer descriptor's range
 //     check returns 0 for them without a memory access, which is exactly the zero-padding rule of
 //     ms_deform_im2col_cuda.cuh:44-67, so the inner loop has no branches;

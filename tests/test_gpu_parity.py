@@ -84,6 +84,28 @@ def test_msda_forward_bf16(rd):
     assert (err <= 2.0 ** -8 * np.abs(ref) + 1e-3).all(), err.max()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_msda_forward_inputs_not_16_byte_aligned(rd, dtype):
+    """The 4-level kernel reads a lane's share of the locations / weights as 16-byte vectors; tensors that start 8 bytes into a
+    16-byte line (legal: the operator asks for natural alignment only) take the run-time-level instantiation -- same result."""
+    value, shp, start, loc, attn = make_msda_inputs(2, 301, [(25, 42), (13, 21), (7, 11), (4, 6)], seed=11)
+    v = value.to(dtype).to(DEV)
+    args = (shp.to(DEV), start.to(DEV))
+    want = rd.ms_deform_attn_forward(v, *args, loc.to(DEV), attn.to(DEV), 64)
+
+    def shifted(t, n):                      # the same values, starting n elements into a fresh buffer
+        buf = torch.empty(t.numel() + n, dtype=t.dtype, device=DEV)
+        view = buf[n:].view(t.shape)
+        view.copy_(t)
+        return view
+    loc8, attn8 = shifted(loc, 2), shifted(attn, 2)
+    assert loc8.data_ptr() % 16 == 8 and attn8.data_ptr() % 16 == 8 and loc8.is_contiguous()
+    got = rd.ms_deform_attn_forward(v, *args, loc8, attn8, 64)
+    assert torch.equal(got, want)            # same per-corner arithmetic, same order of summation
+    got = rd.ms_deform_attn_forward(v, *args, loc8, attn.to(DEV), 64)
+    assert torch.equal(got, want)
+
+
 def test_msda_forward_nan_and_far_locations(rd):
     """NaN / huge locations contribute zero (CUDA-op guard) and never fault."""
     value, shp, start, loc, attn = make_msda_inputs(1, 16, [(8, 12), (4, 6), (2, 3), (1, 2)], seed=9)

@@ -154,8 +154,8 @@ class RelationTransformerEncoderLayer(nn.Module):
             query = add_norm(self.norm1, query, attn)
         if _fused_ffn_applies(self.linear1, self.linear2, query) and os.environ.get("RDETR_FFN_LN", "0") == "1":
             # opt-in: feed-forward block, residual, LayerNorm (and the next layer's query + pos) in ONE kernel (csrc/ffn.hip).
-            # Correct (tests/test_gpu_glue.py) but 1 % slower than fused FFN + the add+LayerNorm kernel: the epilogue's
-            # registers make the compiler spill inside the MFMA loop
+            # Correct (tests/test_gpu_glue.py) but 3-6 % slower in the stack than fused FFN + the add+LayerNorm kernel: the
+            # epilogue runs with the matrix pipe idle, the separate kernel overlaps the other image group
             return ops.ffn_ln_k256(query, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                                    self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, pos=next_pos)
         ffn = feed_forward(self.linear1, self.linear2, query)

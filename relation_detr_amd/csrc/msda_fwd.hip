@@ -15,8 +15,9 @@
 //   * the per-(query, point) bilinear set-up (pixel coords, 4 corner byte offsets, 4 corner weights
 //     already multiplied by the attention weight) is computed ONCE by one lane and staged in LDS,
 //     then broadcast to the lanes of the row with two LDS reads per point.  With 4 levels a lane prepares
-//     4 consecutive points (one level), so its locations / weights arrive with 3 vector loads: the kernel
-//     is bound by the NUMBER of vector-memory instructions (16 clocks each in the texture addresser);
+//     4 consecutive points (one level), so its locations / weights arrive with 3 vector loads (every
+//     vector-memory instruction costs 12-16 clocks in the texture addresser, whatever it moves), and
+//     the 4 levels' constants come by scalar loads: no LDS table, no barrier in front of the inputs;
 //   * bf16: the weighted sum runs on the matrix cores -- v_mfma_f32_4x4x4_16b_bf16 is 16 independent
 //     4x4x4 products, one per query; the four 16-byte loads of a lane are re-paired by v_perm_b32 into
 //     the B operand, the corner weights (bf16 high + low parts) are the A operand (mfma_point below);
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     constexpr int kPtsPerLane = LT ? (LT * kPoints + kSub - 1) / kSub : (kMaxLevels * kPoints) / kSub;
     // LT == 4: a lane prepares kPtsPerLane CONSECUTIVE points (4 = one level for bf16, 2 for fp32), so that its share of the
     // locations / weights (or raw offsets / logits / reference point) arrives with 3 vector loads instead of 8-12 narrow ones
-    // -- the kernel is bound by the number of vector-memory instructions.  Otherwise points sub, sub + kSub, ...
+    // -- the texture addresser's instruction rate is one of the kernel's three co-limiters.  Otherwise points sub, sub + kSub, ...
     constexpr bool kConsec = LT == 4;
     constexpr bool kMM = sizeof(T) == 2;         // bf16: the weighted sum on the matrix cores (mfma_point)
     const int L = LT ? LT : L_rt;
@@ -220,12 +221,31 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     __shared__ f32x4 stage_wgt[kWavesPerBlock][kStageLevels * kPoints * kSlots];
 
     const int tid = threadIdx.x;
-    if (tid < L) {
-        lvl.h[tid] = (int)shapes[2 * tid];
-        lvl.w[tid] = (int)shapes[2 * tid + 1];
-        lvl.start[tid] = (int)level_start[tid];
+    if constexpr (!kConsec) {
+        if (tid < L) {
+            lvl.h[tid] = (int)shapes[2 * tid];
+            lvl.w[tid] = (int)shapes[2 * tid + 1];
+            lvl.start[tid] = (int)level_start[tid];
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    // kConsec: no table in LDS and no barrier -- a wave starts on its inputs at once.  The 4 levels' constants come by scalar
+    // loads (uniform addresses) and a lane selects those of ITS level; a memory round trip + barrier in front of every
+    // workgroup's input loads was a third of the launch.
+    int my_h = 0, my_w = 0, my_start = 0;
+    if constexpr (kConsec) {
+        const int my_level = ((int)(threadIdx.x % kSub) * kPtsPerLane) / kPoints;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int h = (int)shapes[2 * l], w = (int)shapes[2 * l + 1], st = (int)level_start[l];
+            my_h = my_level == l ? h : my_h;
+            my_w = my_level == l ? w : my_w;
+            my_start = my_level == l ? st : my_start;
+        }
+    }
+    auto level_h = [&](int l) { return kConsec ? my_h : lvl.h[l]; };
+    auto level_w = [&](int l) { return kConsec ? my_w : lvl.w[l]; };
+    auto level_start_of = [&](int l) { return kConsec ? my_start : lvl.start[l]; };
 
     // logical block -> (image b, head m, tile of consecutive queries); tiles of one (b, m) are consecutive
     const int logical = xcd_contiguous_block(blockIdx.x, nblk);
@@ -309,8 +329,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             }
             pa[k] = pa[k] / sum;
             if (ref_dim == 2) {
-                pxy[k].x = rc.x + pxy[k].x / (float)lvl.w[l];
-                pxy[k].y = rc.y + pxy[k].y / (float)lvl.h[l];
+                pxy[k].x = rc.x + pxy[k].x / (float)level_w(l);
+                pxy[k].y = rc.y + pxy[k].y / (float)level_h(l);
             } else {
                 pxy[k].x = rc.x + pxy[k].x * (1.0f / kPoints) * rc.z * 0.5f;
                 pxy[k].y = rc.y + pxy[k].y * (1.0f / kPoints) * rc.w * 0.5f;
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             const f32x2 xy = pxy[k];
             const float a = pa[k];
             const int l = pt / kPoints;
-            const int h = lvl.h[l], w = lvl.w[l];
+            const int h = level_h(l), w = level_w(l);
             const float x = xy.x * (float)w - 0.5f;
             const float y = xy.y * (float)h - 0.5f;
             const bool inside = qok && (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);   // false for NaN
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
             const bool okx0 = inside && x0 >= 0, okx1 = inside && x0 + 1 <= w - 1;
             const bool oky0 = y0 >= 0, oky1 = y0 + 1 <= h - 1;
-            const unsigned base = (unsigned)(lvl.start[l] + y0 * w + x0) * pixb;
+            const unsigned base = (unsigned)(level_start_of(l) + y0 * w + x0) * pixb;
             const unsigned rowb = (unsigned)w * pixb;
             u32x4 o;
             o.x = (okx0 && oky0) ? base : kInvalidOffset;
@@ -359,7 +379,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             o.z = (okx0 && oky1) ? base + rowb : kInvalidOffset;
             o.w = (okx1 && oky1) ? base + rowb + pixb : kInvalidOffset;
             if (pad_mask) {                  // key_padding_mask: a padded pixel's projected value row counts as zero
-                const unsigned char *mp = pad_mask + (size_t)b * S + (lvl.start[l] + y0 * w + x0);     // (ms_deform_attn.py:316-319)
+                const unsigned char *mp = pad_mask + (size_t)b * S + (level_start_of(l) + y0 * w + x0);     // (ms_deform_attn.py:316-319)
                 if (okx0 && oky0 && mp[0]) o.x = kInvalidOffset;
                 if (okx1 && oky0 && mp[1]) o.y = kInvalidOffset;
                 if (okx0 && oky1 && mp[w]) o.z = kInvalidOffset;

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     // -- the texture addresser's instruction rate is one of the kernel's three co-limiters.  Otherwise points sub, sub + kSub, ...
     constexpr bool kConsec = LT == 4;
     constexpr bool kMM = sizeof(T) == 2;         // bf16: the weighted sum on the matrix cores (mfma_point)
+    constexpr bool kFast = FUSED && sizeof(T) == 2;      // bf16 producer inputs: see the softmax below
     const int L = LT ? LT : L_rt;
     const int LP = L * kPoints;
 
@@ -305,11 +306,16 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < kPtsPerLane; ++k) {
-            pa[k] = expf(pa[k] - mx);            // exp(-inf) = 0 for the padding slots
+            // exp(-inf) = 0 for the padding slots.  bf16 producer inputs (kFast): the hardware exponential and, below, products
+            // with reciprocals instead of 12 fp32 divisions per lane -- a tenth of the wave's vector-ALU instructions for
+            // differences of an ulp of fp32 under inputs that carry 8 bits; the fp32 kernel keeps the reference's operations
+            pa[k] = kFast ? __builtin_amdgcn_exp2f((pa[k] - mx) * 1.44269504088896341f) : expf(pa[k] - mx);
             sum += pa[k];
         }
         sum = group_sum<kSub>(sum);
+        const float inv_sum = 1.0f / sum;
         f32x4 rc = {0.f, 0.f, 0.f, 0.f};          // kConsec: the lane's points share a level -> one reference point
+        const float inv_w = kConsec ? 1.0f / (float)level_w(0) : 0.f, inv_h = kConsec ? 1.0f / (float)level_h(0) : 0.f;
         if constexpr (kConsec) {
             const float *rp = ref + (row * L + point_of(0) / kPoints) * (size_t)ref_dim;
             if (ref_dim == 2) {
@@ -327,10 +333,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
                 const float *rp = ref + (row * L + l) * (size_t)ref_dim;
                 rc = ref_dim == 2 ? f32x4{rp[0], rp[1], 0.f, 0.f} : f32x4{rp[0], rp[1], rp[2], rp[3]};
             }
-            pa[k] = pa[k] / sum;
+            pa[k] = kFast ? pa[k] * inv_sum : pa[k] / sum;
             if (ref_dim == 2) {
-                pxy[k].x = rc.x + pxy[k].x / (float)level_w(l);
-                pxy[k].y = rc.y + pxy[k].y / (float)level_h(l);
+                if (kFast && kConsec) {
+                    pxy[k].x = rc.x + pxy[k].x * inv_w;
+                    pxy[k].y = rc.y + pxy[k].y * inv_h;
+                } else {
+                    pxy[k].x = rc.x + pxy[k].x / (float)level_w(l);
+                    pxy[k].y = rc.y + pxy[k].y / (float)level_h(l);
+                }
             } else {
                 pxy[k].x = rc.x + pxy[k].x * (1.0f / kPoints) * rc.z * 0.5f;
                 pxy[k].y = rc.y + pxy[k].y * (1.0f / kPoints) * rc.w * 0.5f;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does HIP graph capture survive a NESTED stream fork (origin -> group stream -> side stream -> join)?  One variant per run:
-    python3 tools/exp_nested_fork.py <variant>      variants: flat | nested_events | nested_waitstream | nested_gemm | nested_multi | sibling"""
+    python3 tools/exp_nested_fork.py <variant> [capture_error_mode]      variants: flat | nested_events | nested_waitstream | nested_gemm | nested_multi | sibling"""
 import sys
 
 import torch
@@ -81,7 +81,8 @@ def main():
     torch.cuda.current_stream().wait_stream(warm)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    mode = sys.argv[2] if len(sys.argv) > 2 else "thread_local"
+    with torch.cuda.graph(g, capture_error_mode=mode):
         out = body()
     g.replay()
     torch.cuda.synchronize()

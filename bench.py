@@ -1,9 +1,12 @@
 #!/usr/bin/env python
 """Benchmark of the Relation-DETR hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--queries 900] [--batch 4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--queries 900] [--batch 4] [--config r50|focalnet]
 
-Workload (BASELINE.json configs[1]): relation_detr_resnet50_800_1333 -- padded image 800x1344, 4-level
+--config focalnet = BASELINE.json configs[4] per rank: relation_detr_focalnet_large_lrf_fl4_1200_2000, padded image
+1216x2016, 5-level pyramid (304,504)(152,252)(76,126)(38,63)(19,32), S = 204,098 tokens, 900 queries, 2 images per GPU.
+
+Default workload (BASELINE.json configs[1]): relation_detr_resnet50_800_1333 -- padded image 800x1344, 4-level
 pyramid (100,168)(50,84)(25,42)(13,21), S = 22,323 tokens, 256 channels, 8 heads x 32, 4 points, d_ffn 2048,
 6 encoder + 6 decoder layers, 91 classes, N_q two-stage queries (900 = what the reference config runs;
 BASELINE.json's "300 queries" = detections kept per image, also selectable with --queries 300), batch 4 per GPU.
@@ -31,10 +34,14 @@ import sys
 import tempfile
 import time
 
-# The dense layers of the stack are library GEMMs (hipBLASLt / rocBLAS): let PyTorch's TunableOp pick the fastest library
-# kernel per GEMM shape during the warm-up steps (about 20 shapes, ~5 s; measured +3.6 % images/s).  Must be set before
-# torch is imported; anything the caller has set wins.  RDETR_BENCH_TUNABLEOP=0 turns it off.
-if os.environ.get("RDETR_BENCH_TUNABLEOP", "1") != "0":
+# The dense layers of the stack are library GEMMs (hipBLASLt / rocBLAS).  PyTorch's TunableOp can pick the fastest library
+# kernel per GEMM shape during the warm-up steps (about 20 shapes, ~5 s; +1.5-3.6 % images/s) -- OPT-IN
+# (RDETR_BENCH_TUNABLEOP=1, set before torch is imported): `value` is measured with the library's own heuristics, the tuned
+# rate is a side value from a child process (`value_gemm_tuned`).  Round 2's headline depended on tuning, and tuning is what
+# faulted the GPU twice in round 2 (TunableOp undersizes its scratch copy of a strided-batched operand whose leading
+# dimension exceeds its row length, DESIGN.md 5 -- the operands this package hands the library are dense now, but the
+# headline should not depend on a tuner).
+if os.environ.get("RDETR_BENCH_TUNABLEOP", "0") == "1":
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "30")
@@ -50,8 +57,16 @@ sys.path.insert(0, ROOT)
 R50_SHAPES = [(100, 168), (50, 84), (25, 42), (13, 21)]
 HBM_PEAK = 8.0e12           # B/s, MI355X spec (MI355X_MICROARCH.md)
 METRIC = "images/sec @ 800\u00d71333, 300 queries, R50 4-level; achieved HBM GB/s"      # BASELINE.json, verbatim
-ROOFLINE_KERNEL = ("msda_fwd_qrun_kernel<bf16, L=4> on the head-major value [B,H,S,D] the module path's value projection writes "
+ROOFLINE_KERNEL = ("msda_fwd_qrun_kernel<bf16, L=%d> on the head-major value [B,H,S,D] the module path's value projection writes "
                    "(encoder shape, B=%d; operator form with materialised locations / weights = SURVEY 8d's bytes)")
+# padded pyramid per reference config; `batch` = images per GPU
+CONFIGS = {
+    "r50": dict(name="relation_detr_resnet50_800_1333", shapes=R50_SHAPES, image=(800, 1333), batch=4, metric=METRIC),
+    "focalnet": dict(name="relation_detr_focalnet_large_lrf_fl4_1200_2000",
+                     shapes=[(304, 504), (152, 252), (76, 126), (38, 63), (19, 32)], image=(1200, 2000), batch=2,
+                     metric="images/sec @ 1200\u00d72000, 900 queries, FocalNet-L 5-level (BASELINE.json configs[4], per rank); "
+                            "achieved HBM GB/s"),
+}
 
 
 def msda_algorithmic_bytes(B, S, Nq, L, P, H, D, value_bytes):
@@ -60,42 +75,49 @@ def msda_algorithmic_bytes(B, S, Nq, L, P, H, D, value_bytes):
     return B * (touched * value_bytes + Nq * H * L * P * 2 * 4 + Nq * H * L * P * 4 + Nq * H * D * value_bytes)
 
 
-def build_pyramid(B, dev, seed, dtype=torch.float32):
+def build_pyramid(B, dev, seed, dtype=torch.float32, shapes=R50_SHAPES):
     """Synthetic multi-level features / masks / position embeddings: N(0,1) features,
     all-valid masks, N(0,1) position embeddings."""
     g = torch.Generator().manual_seed(seed)
-    feats = [torch.randn(B, 256, h, w, generator=g).to(dev, dtype) for h, w in R50_SHAPES]
-    pos = [torch.randn(B, 256, h, w, generator=g).to(dev, dtype) for h, w in R50_SHAPES]
-    masks = [torch.zeros(B, h, w, dtype=torch.bool, device=dev) for h, w in R50_SHAPES]
+    feats = [torch.randn(B, 256, h, w, generator=g).to(dev, dtype) for h, w in shapes]
+    pos = [torch.randn(B, 256, h, w, generator=g).to(dev, dtype) for h, w in shapes]
+    masks = [torch.zeros(B, h, w, dtype=torch.bool, device=dev) for h, w in shapes]
     return feats, masks, pos
 
 
-def build_network(Nq, seed=0, **classes):
-    """Random-init RelationTransformer of the R50 config; fresh MSDA modules have zero offset / attention weights
-    (ms_deform_attn.py:268,279-280), so those get a trained-like spread to make the gather data dependent."""
+def build_network(Nq, seed=0, num_levels=4, class_scale=1.0, **classes):
+    """Random-init RelationTransformer of the R50 / FocalNet-L config (they differ in the level count only,
+    configs/relation_detr/relation_detr_focalnet_large_lrf_fl4_1200_2000.py:20-29); fresh MSDA modules have zero offset /
+    attention weights (ms_deform_attn.py:268,279-280), so those get a trained-like spread to make the gather data dependent.
+    ``class_scale``: factor on the weights of every class head (encoder, decoder layers, hybrid).  At 1.0 (the init the
+    reference uses, and what `value` is measured with) all class logits sit within a few 1e-2 of the prior bias, below bf16
+    resolution; tests that compare DETECTIONS between two arithmetic routes use a larger spread (tests/test_gpu_fullsize.py)."""
     from relation_detr_amd.transformer import build_relation_transformer
     torch.manual_seed(seed)
     net = build_relation_transformer(num_classes=91, d_ffn=2048, enc_layers=6, dec_layers=6, num_queries=Nq,
-                                     hybrid_num_proposals=1500, **classes)
+                                     hybrid_num_proposals=1500, num_levels=num_levels, **classes)
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for name, mod in net.named_modules():
             if hasattr(mod, "sampling_offsets"):
                 mod.sampling_offsets.weight.copy_(torch.randn(mod.sampling_offsets.weight.shape, generator=g) * 0.02)
                 mod.attention_weights.weight.copy_(torch.randn(mod.attention_weights.weight.shape, generator=g) * 0.05)
+        if class_scale != 1.0:
+            for head in (net.encoder_class_head, net.hybrid_class_head, *net.decoder.class_head):
+                head.weight.mul_(class_scale)
     return net.eval()
 
 
-def encoder_kernel_inputs(B, dev, dtype):
+def encoder_kernel_inputs(B, dev, dtype, level_shapes=R50_SHAPES):
     """Inputs of the dominant kernel at the encoder shape: pixel-centre reference points + N(0, (k/W_l)^2)
     offsets for point k = 1..4, softmaxed N(0,1) weights (SURVEY.md section 8d / BASELINE.md section 3)."""
     g = torch.Generator().manual_seed(123)
-    shapes = torch.tensor(R50_SHAPES, dtype=torch.int64)
+    shapes = torch.tensor(level_shapes, dtype=torch.int64)
     areas = shapes[:, 0] * shapes[:, 1]
     start = torch.cat([areas.new_zeros(1), areas.cumsum(0)[:-1]])
-    S, L = int(areas.sum()), len(R50_SHAPES)
+    S, L = int(areas.sum()), len(level_shapes)
     refs = []
-    for h, w in R50_SHAPES:
+    for h, w in level_shapes:
         ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
         refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
     ref = torch.cat(refs, 0)
@@ -109,12 +131,12 @@ def encoder_kernel_inputs(B, dev, dtype):
     return value, shapes.to(dev), start.to(dev), loc, attn, S, L
 
 
-def time_encoder_kernel(B, dev, dtype, reps=20, layout=None):
+def time_encoder_kernel(B, dev, dtype, reps=20, layout=None, level_shapes=R50_SHAPES):
     """Average duration of the dominant kernel from device events recorded on the stream it is launched on.
     layout None = the one the stack runs the kernel in: head-major [B,H,S,D] for bf16 (written by the value projection's
     epilogue, relation_detr_amd/ms_deform_attn.py), the reference operator's [B,S,H,D] for fp32."""
     import relation_detr_amd as rd
-    value, shapes, start, loc, attn, S, L = encoder_kernel_inputs(B, dev, dtype)
+    value, shapes, start, loc, attn, S, L = encoder_kernel_inputs(B, dev, dtype, level_shapes)
     if layout is None:
         layout = "bhsd" if dtype == torch.bfloat16 else "bshd"
     if layout == "bhsd":
@@ -132,14 +154,15 @@ def time_encoder_kernel(B, dev, dtype, reps=20, layout=None):
     return e0.elapsed_time(e1) / reps * 1e-3, S, L
 
 
-def pmc_traffic(dtype_name, B):
+def pmc_traffic(dtype_name, B, config="r50"):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read inside a timed run (separate
     `rocprofv3 --pmc` passes, MI355X_MICROARCH.md), so the live line carries the figure of the last committed PMC pass
     of this kernel (tools/profile_msda.py -> profiles/r02/pmc_msda_fwd_B4_encoder.json) TOGETHER with the commit it was
     taken at; `traffic` is null when no pass of the current default kernel is on file.
     traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE doubled as the guide prescribes for gfx950."""
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_msda_fwd_B4_encoder.json")
-    if B != 4 or not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_msda_fwd_B4_encoder.json") for r in ("r03", "r02"))
+                 if os.path.exists(q)), None)
+    if B != 4 or path is None or config != "r50":
         return {"traffic": None}
     rec = json.load(open(path))
     c = rec.get("per_launch_mean", {}).get(dtype_name)
@@ -149,7 +172,7 @@ def pmc_traffic(dtype_name, B):
             "traffic_kernel": rec.get("kernel", "unknown")}
 
 
-def cpu_baseline(Nq, budget_s=25.0):
+def cpu_baseline(Nq, budget_s=25.0, cfg=None):
     """The same transformer stack with the oracle's PyTorch-CPU operators (per-level grid_sample + stack + weighted
     sum, materialised relation embedding, softmax attention) on the host cores: ONE image per pass, repeated until
     ~budget_s of CPU work; returns images/s."""
@@ -159,16 +182,19 @@ def cpu_baseline(Nq, budget_s=25.0):
     # oversubscribe (measured: 62 s/image with 256 threads)
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("RDETR_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
-    net = build_network(Nq, 0, msda_cls=OracleMSDA, self_attn_cls=OracleSelfAttention, relation_cls=OracleRelation)
-    feats, masks, pos = build_pyramid(1, "cpu", 7)
-    sizes = torch.tensor([[800, 1333]])
+    cfg = cfg or CONFIGS["r50"]
+    net = build_network(Nq, 0, num_levels=len(cfg["shapes"]), msda_cls=OracleMSDA, self_attn_cls=OracleSelfAttention,
+                        relation_cls=OracleRelation)
+    feats, masks, pos = build_pyramid(1, "cpu", 7, shapes=cfg["shapes"])
+    sizes = torch.tensor([list(cfg["image"])])
 
     def one_image():
         with torch.no_grad():
             classes, coords = net(feats, masks, pos)[:2]
             return select_detections(classes[-1], coords[-1], sizes)
 
-    one_image()                                             # warm
+    if len(cfg["shapes"]) == 4:
+        one_image()                                         # warm (the 5-level image alone is ~30 s of CPU work: timed cold)
     n, t0 = 0, time.perf_counter()
     while True:
         one_image()
@@ -207,38 +233,70 @@ def detection_drift(det_a, det_b, iou_thr=0.9):
             "max_score_dist": float(dscore[ok].max()) if n_ok else None}
 
 
-def _free_port():
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def init_process_group(backend, rank, world, **kw):
+    """Rendezvous of the ranks.  Launched by torch.distributed.run (or any launcher that exports MASTER_ADDR / MASTER_PORT):
+    env://, as the driver's contract says.  Launched by this script's own launcher (`launch_ranks`) or as a single forced rank:
+    a FILE store in a fresh private directory -- no TCP port is picked, so there is no window in which another process
+    can take a port between choosing it and binding it."""
+    path = os.environ.get("RDETR_BENCH_INIT_FILE")
+    if path is None and "MASTER_PORT" not in os.environ:
+        if world != 1:
+            raise SystemExit("[bench] no rendezvous: set MASTER_ADDR / MASTER_PORT (torch.distributed.run does) or start the "
+                             "ranks with `python bench.py --gpus N`")
+        path = os.path.join(tempfile.mkdtemp(prefix="rdetr_bench_"), "store")
+    if path is not None:
+        dist.init_process_group(backend, init_method="file://" + path, rank=rank, world_size=world, **kw)
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, deadline_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one rank per GPU
-    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), BEFORE anything in this process touches the GPU;
-    wait for all of them; exit code 0 only if every rank succeeded.  The parent never initialises HIP and is never
-    replaced by another program (the reference's launcher for the same job is `accelerate launch`, test.py:71-113)."""
+    (RANK / LOCAL_RANK / WORLD_SIZE and the rendezvous file in their environment), BEFORE anything in this process touches
+    the GPU.  All children are polled together: the first rank that exits non-zero (or the optional deadline) ends the
+    others at once -- they would otherwise sit in a collective until the RCCL timeout -- and the launcher returns 1.
+    The parent never initialises HIP and is never replaced by another program (the reference's launcher for the same job is
+    `accelerate launch`, test.py:71-113)."""
+    import shutil
     import subprocess
-    env = dict(os.environ)
-    env.update(WORLD_SIZE=str(n), MASTER_ADDR=env.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(_free_port()),
+    store_dir = tempfile.mkdtemp(prefix="rdetr_bench_")
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_PORT",)}
+    env.update(WORLD_SIZE=str(n), RDETR_BENCH_INIT_FILE=os.path.join(store_dir, "store"),
                HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RDETR_BENCH_CHILD="1")
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=e))
-    codes = []
+    t0 = time.monotonic()
+    failed = None
     try:
-        for p in procs:
-            codes.append(p.wait())
-    except BaseException:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = f"ranks failed (rank, exit code): {bad}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if deadline_s is not None and time.monotonic() - t0 > deadline_s:
+                failed = f"deadline of {deadline_s:.0f} s passed with ranks {[r for r, c in enumerate(codes) if c is None]} still running"
+                break
+            time.sleep(0.05)
+    finally:
         for p in procs:                                     # the exact processes this function started
             if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
                 p.kill()
-        raise
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+                p.wait()
+        shutil.rmtree(store_dir, ignore_errors=True)
+    if failed:
+        print(f"[bench] {failed}; remaining ranks ended", file=sys.stderr)
         return 1
     return 0
 
@@ -249,10 +307,10 @@ def dry_run(args, world, rank):
     rank-0 JSON line -- around a stand-in step that only fabricates a [B,300,6] tensor.  It measures nothing about the
     hot path (the product has no CPU path) and says so in the line; tests/test_dist_gloo.py drives it with 2 ranks."""
     from relation_detr_amd.dist import gather_detections
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
     if world > 1 or os.environ.get("RDETR_BENCH_FORCE_DIST") == "1":
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        init_process_group("gloo", rank, world)
+    if os.environ.get("RDETR_BENCH_DRY_FAIL_RANK") == str(rank):       # test hook: this rank dies before its first collective
+        raise SystemExit(3)
     B = args.batch
     ids = torch.arange(B) + rank * B
 
@@ -318,7 +376,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--queries", type=int, default=900)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 4 for r50, 2 for focalnet)")
+    ap.add_argument("--config", default="r50", choices=sorted(CONFIGS), help="r50 = BASELINE.json configs[1] (default); "
+                    "focalnet = configs[4] per rank (5 levels, 1200x2000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--no-extras", action="store_true", help="skip the 300-query / fp32 / drift side measurements")
@@ -327,6 +387,17 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    cfg = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = cfg["batch"]
+    tuned = os.environ.get("PYTORCH_TUNABLEOP_ENABLED", "0") == "1"
+    if args.dtype == "fp32" and not args.no_graph and not tuned:
+        # Capturing the fp32 stack with the library's default GEMM selection stopped making progress on this image in round 2
+        # (full size; cause in DESIGN.md 5).  No configuration of this script may hang a GPU: fp32 without tuned GEMMs is
+        # enqueued from Python.  RDETR_BENCH_FP32_GRAPH=1 forces the capture (tools/exp_fp32_capture.py runs that under a timeout).
+        if os.environ.get("RDETR_BENCH_FP32_GRAPH") != "1":
+            print("[bench] --dtype fp32 without GEMM tuning: running eagerly (--no-graph)", file=sys.stderr)
+            args.no_graph = True
 
     # ---- one process per GPU -------------------------------------------------------------------------------------------
     # Launched by torch.distributed.run (RANK / WORLD_SIZE in the environment): this process is one rank.  Launched bare
@@ -347,10 +418,8 @@ def main():
     use_dist = world > 1 or os.environ.get("RDETR_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(_free_port()) if world == 1 else "29541")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        init_process_group("nccl", rank, world, device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -362,8 +431,8 @@ def main():
 
     B, Nq = args.batch, args.queries
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    feats, masks, pos = build_pyramid(B, dev, seed=1000 + rank, dtype=dtype)       # each rank owns its image block
-    sizes = torch.tensor([[800, 1333]] * B, device=dev)
+    feats, masks, pos = build_pyramid(B, dev, seed=1000 + rank, dtype=dtype, shapes=cfg["shapes"])   # each rank owns its image block
+    sizes = torch.tensor([list(cfg["image"])] * B, device=dev)
     img_ids = torch.arange(B, device=dev) + rank * B
     L = len(feats)
 
@@ -376,7 +445,7 @@ def main():
 
     def make_runner(queries, net_dtype, inputs):
         """(callable, launch mode) of the whole stack + top-300 detections for one network configuration."""
-        net = build_network(queries, 0).to(dev).to(net_dtype)           # same weights on every rank
+        net = build_network(queries, 0, num_levels=L).to(dev).to(net_dtype)           # same weights on every rank
 
         @torch.no_grad()
         def forward_images(*t):                             # device tensors in and out
@@ -424,8 +493,9 @@ def main():
         el = max(per_rank)                                  # MAX over ranks
 
     note(f"timed loop done: {world * B * args.steps / el:.1f} images/s; dominant kernel")
-    t_kernel, S, L = time_encoder_kernel(B, dev, dtype)
-    t_kernel_bshd = time_encoder_kernel(B, dev, dtype, layout="bshd")[0] if args.dtype == "bf16" else None
+    t_kernel, S, L = time_encoder_kernel(B, dev, dtype, level_shapes=cfg["shapes"])
+    t_kernel_bshd = time_encoder_kernel(B, dev, dtype, layout="bshd", level_shapes=cfg["shapes"])[0] if args.dtype == "bf16" else None
+    t_kernel_fp32 = time_encoder_kernel(B, dev, torch.float32, level_shapes=cfg["shapes"])[0] if args.dtype == "bf16" else None
     note("side measurements")
     alg = msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2 if args.dtype == "bf16" else 4)
 
@@ -434,7 +504,7 @@ def main():
     #    and keeps 300 detections (what `value` measures): the same stack with 300 two-stage queries -> value_300_queries;
     #  * the reference's gather is fp32 even under bf16 autocast (ms_deform_attn.py:360): the fp32 stack's rate, and how far
     #    the bf16 detections are from the fp32 ones on the same images.
-    value_300 = fp32_ips = drift = None
+    value_300 = fp32_ips = drift = value_tuned = None
     extras = world == 1 and rank == 0 and not args.no_extras and os.environ.get("RDETR_BENCH_ALT300", "1") != "0"
     if extras and Nq != 300:
         try:
@@ -447,16 +517,16 @@ def main():
             print(f"[bench] 300-query variant skipped ({type(e).__name__}: {str(e)[:160]})", file=sys.stderr)
     if extras and args.dtype == "bf16":
         # In a CHILD process: the same script with --dtype fp32 on the same synthetic images (same seeds), its detections dumped
-        # for the comparison.  (In-process the fp32 stack would need a third graph capture; fp32 library GEMMs under capture
-        # hang on this image unless TunableOp has picked their kernels, which is what the child's own warm-up does.  A child
-        # that hangs is killed by its timeout and the two fields stay null.)
+        # for the comparison (enqueued from Python: see the fp32 note at the top of main).  A child that does not finish is
+        # ended by its timeout and the two fields stay null.
         import subprocess
         dump = os.path.join(tempfile.gettempdir(), f"rdetr_bench_fp32_dets_{os.getpid()}.pt")
         note("fp32 side run (child process)")
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RDETR_BENCH_CHILD")}
             cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "fp32", "--steps", "5", "--warmup", "2",
-                                 "--queries", str(Nq), "--batch", str(B), "--no-extras", "--no-cpu-baseline", "--dump-dets", dump],
+                                 "--queries", str(Nq), "--batch", str(B), "--config", args.config, "--no-extras",
+                                 "--no-cpu-baseline", "--dump-dets", dump],
                                 env=env, capture_output=True, text=True, timeout=150)
             line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if cp.returncode == 0 and line:
@@ -471,38 +541,62 @@ def main():
             if os.path.exists(dump):
                 os.remove(dump)
 
+    if extras and args.dtype == "bf16" and not tuned and os.environ.get("RDETR_BENCH_TUNED_SIDE", "1") != "0":
+        # The same bf16 run with PyTorch's TunableOp choosing the library GEMM kernels, in a child process (a tuner fault
+        # cannot take the headline down): side value only.
+        import subprocess
+        note("GEMM-tuned side run (child process)")
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RDETR_BENCH_CHILD")}
+            env["RDETR_BENCH_TUNABLEOP"] = "1"
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--steps", str(args.steps),
+                                 "--warmup", str(max(args.warmup, 5)), "--queries", str(Nq), "--batch", str(B), "--config",
+                                 args.config, "--no-extras", "--no-cpu-baseline"],
+                                env=env, capture_output=True, text=True, timeout=200)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode == 0 and line:
+                value_tuned = json.loads(line[-1])["value"]
+            else:
+                print(f"[bench] tuned side run failed (exit {cp.returncode}): {cp.stderr[-300:]}", file=sys.stderr)
+        except (subprocess.TimeoutExpired, OSError) as e:
+            print(f"[bench] tuned side run skipped ({type(e).__name__})", file=sys.stderr)
+
     if rank == 0 and args.dump_dets:
         torch.save(dets_main.detach().float().cpu(), args.dump_dets)
     if rank == 0:
         res = {
-            "metric": METRIC,
+            "metric": cfg["metric"],
             "value": world * B * args.steps / el, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "value_300_queries": value_300,
+            "value_300_queries": value_300, "value_gemm_tuned": value_tuned,
             "world_size_seen": dist.get_world_size() if use_dist else 1,
             "per_rank_images_per_s": [B * args.steps / t for t in per_rank],
-            "config": {"workload": "relation_detr_resnet50_800_1333 transformer stack from feature pyramids: 6 encoder "
-                                   "layers (MSDA self-attn, S=22323) + two-stage top-k + 6 decoder layers (relation-biased "
+            "config": {"workload": f"{cfg['name']} transformer stack from feature pyramids: 6 encoder "
+                                   f"layers (MSDA self-attn, S={S}, {L} levels) + two-stage top-k + 6 decoder layers (relation-biased "
                                    "self-attn + MSDA cross-attn + box refinement) + top-300 detections; backbone/neck excluded",
                        "batch_per_gpu": B, "global_batch": B * world, "queries": Nq,
                        "queries_note": "value: 900 two-stage queries (what the reference config runs), 300 detections kept; "
                                        "value_300_queries: 300 two-stage queries (BASELINE.json's wording)",
-                       "levels": 4, "fp32_images_per_s": fp32_ips, "bf16_vs_fp32_detections": drift,
+                       "levels": L, "fp32_images_per_s": fp32_ips, "bf16_vs_fp32_detections": drift,
                        "launch": launch, "streams": nstreams,
-                       "gemm_tuning": os.environ.get("PYTORCH_TUNABLEOP_ENABLED", "0") == "1",
+                       "gemm_tuning": tuned,
                        "parallelism": f"image-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": (ROOFLINE_KERNEL % B) if args.dtype == "bf16" else "msda_fwd_qrun_kernel<float, L=4> (encoder shape, B=%d)" % B,
+            "roofline": {"bound": "hbm", "kernel": (ROOFLINE_KERNEL % (L, B)) if args.dtype == "bf16" else "msda_fwd_qrun_kernel<float, L=%d> (encoder shape, B=%d)" % (L, B),
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": alg / t_kernel / HBM_PEAK, **pmc_traffic(args.dtype, B),
+                         "frac": alg / t_kernel / HBM_PEAK, **pmc_traffic(args.dtype, B, args.config),
                          "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3,
+                         "fp32": None if t_kernel_fp32 is None else {
+                             "kernel": "msda_fwd_qrun_kernel<float> on value [B,S,H,D] (the reference operator's own arithmetic, ms_deform_attn.py:360)",
+                             "kernel_ms": t_kernel_fp32 * 1e3, "algorithmic_bytes": msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 4),
+                             "frac": msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 4) / t_kernel_fp32 / HBM_PEAK},
                          "reference_operator_layout_ms": t_kernel_bshd * 1e3 if t_kernel_bshd else None,
                          "reference_operator_layout_note": "same operator on value [B,S,H,D] (the _C contract): LDS-window MFMA "
                                                            "kernel msda_fwd_win_kernel, algo = auto"},
         }
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline")
-            res["cpu_baseline"] = cpu_baseline(Nq)
+            res["cpu_baseline"] = cpu_baseline(Nq, cfg=cfg)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()

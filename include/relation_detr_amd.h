@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RDETR_ABI_VERSION 2
+#define RDETR_ABI_VERSION 3
 
 typedef enum rdetr_status {
     RDETR_OK = 0,
@@ -104,12 +104,20 @@ int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spati
  *                 RDETR_VALUE_BHSD  value [B, H, S, D]: head-major -- one (image, head) plane is contiguous, so the window
  *                                   kernel fills its LDS windows at the contiguous-row rate.  Written by
  *                                   rdetr_value_to_head_major_bf16 (below); fast-path shapes only.
- *   algo          RDETR_MSDA_AUTO    what the plain entry points do: for RDETR_VALUE_BSHD the window kernel where it applies,
- *                                    else (and for RDETR_VALUE_BHSD) the direct kernel -- the faster of the two per layout;
+ *   algo          RDETR_MSDA_AUTO    what the plain entry points do: the direct kernel.  Correct for ANY level table the
+ *                                    reference operator accepts (gaps, overlapping or unordered levels, sum(h*w) < S);
  *                 RDETR_MSDA_DIRECT  csrc/msda_fwd.hip -- the query-run kernel (range-checked global gathers), any Nq, L <= 8;
+ *                 RDETR_MSDA_AUTO_PACKED  the faster kernel per layout: for RDETR_VALUE_BSHD the window kernel where it
+ *                                    applies, else (and for RDETR_VALUE_BHSD) the direct kernel.  Same PRECONDITION as
+ *                                    RDETR_MSDA_WINDOW;
  *                 RDETR_MSDA_WINDOW  csrc/msda_win.hip -- LDS-window MFMA kernel for the ENCODER shape: queries are the
  *                                    pyramid's own pixels in level_start order (Nq == S), L == 4, S >= 4096, no padding
- *                                    mask.  Per 16 x 12 query tile and level a 32-pixel-wide window of the value plane is
+ *                                    mask.  PRECONDITION (the caller's promise -- the level table lives in device memory
+ *                                    and the library never synchronises, so it cannot check): the levels TILE [0, S)
+ *                                    exactly, level_start[l] = sum of h*w of the earlier levels and sum(h*w) == S, and no
+ *                                    level is larger than level 0 (the kernel enumerates its queries as the pixels of the
+ *                                    levels: with gaps or overlaps output rows would be left unwritten or written twice).
+ *                                    rdetr_msda_levels_window_ok() checks a HOST copy of the table.  Per 16 x 12 query tile and level a 32-pixel-wide window of the value plane is
  *                                    copied L2 -> LDS by range-checked LDS-DMA (pixels outside the level arrive as zeros) and
  *                                    gathered from there on the matrix cores; samples outside their window are fetched from
  *                                    global memory, so results never depend on the windows.  RDETR_ERR_UNSUPPORTED for any
@@ -120,6 +128,10 @@ int rdetr_msda_forward_fused_ex_bf16(const uint16_t *value, const int64_t *spati
 #define RDETR_MSDA_AUTO 0
 #define RDETR_MSDA_DIRECT 1
 #define RDETR_MSDA_WINDOW 2
+#define RDETR_MSDA_AUTO_PACKED 3
+/* 1 if a level table (HOST pointers) meets the precondition of RDETR_MSDA_WINDOW / RDETR_MSDA_AUTO_PACKED for a value tensor
+ * with S positions, else 0.  Pure host arithmetic. */
+int rdetr_msda_levels_window_ok(const int64_t *host_spatial_shapes, const int64_t *host_level_start_index, int L, long long S);
 int rdetr_msda_forward_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
                                 const int64_t *level_start_index, const float *sampling_loc, const float *attn_weight, int B,
                                 int S, int H, int D, int L, int Nq, int P, int algo, uint16_t *out, void *stream);

@@ -19,6 +19,9 @@ Fixtures (see tests/golden/README.md):
   g8_transformer_train.npz  the same network in TRAINING mode: denoising queries in front of the matching queries with
                         their visibility mask, the hybrid (one-to-many) branch, all 8 outputs, and autograd gradients
                         of a fixed linear functional of the outputs   (``python oracle/gen_golden.py g8`` writes only it)
+  g9_transformer_l5.npz the eval forward with FIVE feature levels (the FocalNet-L configuration's level count,
+                        configs/relation_detr/relation_detr_focalnet_large_lrf_fl4_1200_2000.py:24,35-70) on a padded
+                        3-image batch                                 (``python oracle/gen_golden.py g9`` writes only it)
 """
 import ast
 import os
@@ -231,6 +234,7 @@ def main():
                         out_classes=oc.numpy(), out_coords=ob.numpy(), enc_classes=ec.numpy(), enc_coords=eb.numpy())
 
     golden_g8(R)
+    golden_g9(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
@@ -295,8 +299,47 @@ def golden_g8(R):
         grad_dn_label=dn_label.grad.numpy(), grad_dn_box=dn_box.grad.numpy())
 
 
+def golden_g9(R):
+    """RelationTransformer with num_feature_levels = 5 in eval mode (relation_transformer.py:59-160; the FocalNet-L config's
+    level count: the extra level is the neck's stride-2 conv of the last one, channel_mapper.py:43-59 -> (2,3) -> (1,2))."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from helpers import synthetic_state_dict
+    g = torch.Generator().manual_seed(20240609)
+    shapes, _, _ = pyramid([(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)])
+    nlev, nq = 5, 24
+    enc = R.RelationTransformerEncoder(R.RelationTransformerEncoderLayer(256, 64, 0.0, 8, torch.nn.ReLU(inplace=True), nlev, 4), 2)
+    dec = R.RelationTransformerDecoder(R.RelationTransformerDecoderLayer(256, 64, 8, 0.0, torch.nn.ReLU(inplace=True), nlev, 4), 3, 11)
+    tr = R.RelationTransformer(enc, dec, 11, nlev, nq, 30).eval()
+    tr.load_state_dict(synthetic_state_dict(tr.state_dict()))
+    Bt = 3
+    feats = [torch.randn(Bt, 256, h, w, generator=g) for h, w in shapes.tolist()]
+    pos = [torch.randn(Bt, 256, h, w, generator=g) * 0.5 for h, w in shapes.tolist()]
+    masks = []
+    for h, w in shapes.tolist():                                   # image 1 padded right, image 2 padded bottom + right
+        mk = torch.zeros(Bt, h, w, dtype=torch.bool)
+        if w > 2:
+            mk[1, :, int(round(w * 0.75)):] = True
+            mk[2, :, int(round(w * 0.9)):] = True
+        if h > 1:
+            mk[2, int(round(h * 0.6)):, :] = True
+        masks.append(mk)
+    with torch.no_grad():
+        oc, ob, ec, eb = tr(feats, masks, pos)[:4]
+    np.savez_compressed(os.path.join(OUT, "g9_transformer_l5.npz"), shapes=shapes.numpy(),
+                        **{f"feat{i}": f.numpy() for i, f in enumerate(feats)},
+                        **{f"pos{i}": f.numpy() for i, f in enumerate(pos)},
+                        **{f"mask{i}": f.numpy() for i, f in enumerate(masks)},
+                        param_names=np.array(list(tr.state_dict().keys())),
+                        param_shapes=np.array([";".join(map(str, v.shape)) for v in tr.state_dict().values()]),
+                        out_classes=oc.numpy(), out_coords=ob.numpy(), enc_classes=ec.numpy(), enc_coords=eb.numpy())
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["g8"]:
+    if sys.argv[1:] == ["g9"]:
+        torch.manual_seed(0)
+        torch.set_num_threads(4)
+        golden_g9(import_reference()[2])
+    elif sys.argv[1:] == ["g8"]:
         torch.manual_seed(0)
         torch.set_num_threads(4)
         golden_g8(import_reference()[2])

@@ -19,6 +19,7 @@ SIGNATURES = {
     "rdetr_abi_version": [],
     "rdetr_status_string": [_c_int],
     "rdetr_msda_fast_path": [_c_int] * 4,
+    "rdetr_msda_levels_window_ok": [_vp, _vp, _c_int, _c_ll],
     "rdetr_msda_forward_f32": [_vp] * 5 + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_bf16": [_vp] * 5 + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_fused_f32": [_vp] * 6 + [_c_int] * 8 + [_vp, _vp],
@@ -81,8 +82,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.argtypes = argtypes
         fn.restype = ctypes.c_char_p if name == "rdetr_status_string" else (_c_ll if name == "rdetr_topk_workspace_bytes" else _c_int)
-    if lib.rdetr_abi_version() != 2:
-        raise RdetrError(f"ABI version mismatch: library {lib.rdetr_abi_version()}, binding 2")
+    if lib.rdetr_abi_version() != 3:
+        raise RdetrError(f"ABI version mismatch: library {lib.rdetr_abi_version()}, binding 3")
     _lib = lib
     return lib
 

@@ -559,7 +559,8 @@ static int msda_forward(const T *value, int layout, const int64_t *shapes, const
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
     if (layout != RDETR_VALUE_BSHD && layout != RDETR_VALUE_BHSD) return RDETR_ERR_INVALID_ARG;
-    if (algo != RDETR_MSDA_AUTO && algo != RDETR_MSDA_DIRECT && algo != RDETR_MSDA_WINDOW) return RDETR_ERR_INVALID_ARG;
+    if (algo != RDETR_MSDA_AUTO && algo != RDETR_MSDA_DIRECT && algo != RDETR_MSDA_WINDOW && algo != RDETR_MSDA_AUTO_PACKED)
+        return RDETR_ERR_INVALID_ARG;
     if (FUSED && ref_dim != 2 && ref_dim != 4) return RDETR_ERR_INVALID_ARG;
     if (B == 0 || Nq == 0) return RDETR_OK;
     if (!value || !shapes || !level_start || !src_a || !src_b || !out || (FUSED && !ref)) return RDETR_ERR_INVALID_ARG;
@@ -571,10 +572,12 @@ static int msda_forward(const T *value, int layout, const int64_t *shapes, const
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
         if constexpr (sizeof(T) == 2) {
-            // encoder shape (queries = the pyramid's own pixels): the LDS-window MFMA kernel.  AUTO takes it for the reference
-            // operator's layout (measured at BASELINE.json configs[1]: 127-132 us vs 141 us direct) and the direct kernel for the
-            // head-major one (118 us direct vs 127 us window: contiguous head planes halve the lines a gather instruction touches)
-            if ((algo == RDETR_MSDA_WINDOW || (algo == RDETR_MSDA_AUTO && !hm)) && !pad_mask) {
+            // encoder shape (queries = the pyramid's own pixels): the LDS-window MFMA kernel.  It enumerates its queries as the
+            // pixels of the levels, so it is only correct for a level table that tiles [0, S) -- which lives in device memory
+            // and cannot be checked here: plain AUTO therefore never takes it.  AUTO_PACKED (the caller has checked the table,
+            // rdetr_msda_levels_window_ok) takes it for the reference operator's layout (measured at BASELINE.json configs[1]:
+            // 127-132 us vs 141 us direct) and the direct kernel for the head-major one (118 us direct vs 127 us window).
+            if ((algo == RDETR_MSDA_WINDOW || (algo == RDETR_MSDA_AUTO_PACKED && !hm)) && !pad_mask) {
                 const int st = hm ? msda_win_forward<FUSED, true>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S,
                                                                   L, Nq, ld_a, ld_b, out, stream)
                                   : msda_win_forward<FUSED, false>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B,
@@ -636,6 +639,19 @@ __global__ __launch_bounds__(256) void value_to_head_major_kernel(const uint16_t
 }  // namespace rdetr
 
 extern "C" int rdetr_msda_fast_path(int H, int D, int L, int P) { return rdetr::fast_path(H, D, L, P) ? 1 : 0; }
+
+extern "C" int rdetr_msda_levels_window_ok(const int64_t *shapes, const int64_t *level_start, int L, long long S)
+{
+    if (!shapes || !level_start || L <= 0) return 0;
+    long long run = 0;
+    for (int l = 0; l < L; ++l) {
+        const long long h = shapes[2 * l], w = shapes[2 * l + 1];
+        if (h <= 0 || w <= 0 || level_start[l] != run) return 0;
+        if (l > 0 && (h > shapes[0] || w > shapes[1])) return 0;        // the tile tables assume no level outgrows level 0
+        run += h * w;
+    }
+    return run == S ? 1 : 0;
+}
 
 extern "C" int rdetr_msda_forward_f32(const float *value, const int64_t *spatial_shapes,
                                       const int64_t *level_start_index, const float *sampling_loc,

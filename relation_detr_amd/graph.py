@@ -12,6 +12,7 @@ into a hipGraph and replayed with one launch per batch.
 """
 from __future__ import annotations
 
+import threading
 from typing import Callable, Sequence
 
 import torch
@@ -57,28 +58,56 @@ class ImageGroups:
 
 
 class GraphedCall:
+    """Capture ``fn(*example_inputs)`` once, replay it with one launch per call.
+
+    What construction assumes, and enforces (a second GraphedCall warmed up while the first one was
+    replaying on another stream ended in a GPU memory fault):
+      * the DEVICE IS IDLE for this process while a graph is warmed up and captured.  The warm-up runs eagerly on a side
+        stream and allocates from the caching allocator's ordinary pool; host-side caches (packed weights, level tables) are
+        filled by whichever call comes first and are only fenced against the streams that exist at that moment.  A replay of
+        another graph in flight at that time is outside what those fences cover.  So the constructor starts with a device-
+        wide synchronize, and construction and replay exclude each other through one process-wide lock: a replay attempted
+        (from another thread) while some GraphedCall is being built raises instead of racing it;
+      * each instance owns a private memory pool (torch's default for a new CUDAGraph); the tensors it returns live there and
+        are overwritten by its next replay -- two instances never share buffers;
+      * replays of DIFFERENT instances may overlap on different streams once both are built."""
+
+    _build_lock = threading.Lock()
+
     def __init__(self, fn: Callable, example_inputs: Sequence[torch.Tensor], warmup: int = 3):
         if not example_inputs or not all(t.is_cuda for t in example_inputs):
             raise _lib.RdetrError("GraphedCall needs device tensors (there is no CPU path)")
         _lib.load()
         self._fn = fn
         self._inputs = list(example_inputs)             # the captured objects: replay reads these buffers
-        side = torch.cuda.Stream(device=self._inputs[0].device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():  # warm-up outside capture: host-side caches, lazy handles, autotuning
-            for _ in range(max(1, warmup)):
-                fn(*self._inputs)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (the RCCL watchdog of an initialised process group polls events)
-        # must not invalidate the capture
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), torch.no_grad():
-            self._outputs = fn(*self._inputs)
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.RdetrError("GraphedCall cannot be built inside another capture")
+        if not GraphedCall._build_lock.acquire(blocking=False):
+            raise _lib.RdetrError("another GraphedCall is being built (or replayed) on another thread: build graphs one at a "
+                                  "time with the device idle")
+        try:
+            torch.cuda.synchronize()                    # nothing of this process in flight: earlier graphs' replays have drained
+            side = torch.cuda.Stream(device=self._inputs[0].device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():  # warm-up outside capture: host-side caches, lazy handles, autotuning
+                for _ in range(max(1, warmup)):
+                    fn(*self._inputs)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            # thread_local: other threads of the process (the RCCL watchdog of an initialised process group polls events)
+            # must not invalidate the capture
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), torch.no_grad():
+                self._outputs = fn(*self._inputs)
+            torch.cuda.synchronize()
+        finally:
+            GraphedCall._build_lock.release()
 
     def __call__(self, *inputs: torch.Tensor):
         if len(inputs) != len(self._inputs):
             raise _lib.RdetrError(f"expected {len(self._inputs)} tensors, got {len(inputs)}")
+        if GraphedCall._build_lock.locked():
+            raise _lib.RdetrError("a GraphedCall is being built on another thread: replays must wait for it (device idle during capture)")
         for dst, src in zip(self._inputs, inputs):
             if src is not dst:
                 if src.shape != dst.shape or src.dtype != dst.dtype:

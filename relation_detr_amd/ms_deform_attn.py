@@ -10,8 +10,6 @@ optimiser grouping matches on ``sampling_offsets``, optimizer/param_dict.py:82) 
 """
 from __future__ import annotations
 
-import os
-
 import math
 import warnings
 
@@ -19,6 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from . import ops
+from . import options as _options
 
 
 def sampling_locations(reference_points: Tensor, offsets: Tensor, spatial_shapes: Tensor, num_points: int) -> Tensor:
@@ -51,6 +50,7 @@ class MultiScaleDeformableAttention(nn.Module):
         self.num_heads = num_heads
         self.num_levels = num_levels
         self.num_points = num_points
+        self.options = _options.get()          # kernel-routing switches, fixed at construction (options.py)
         self.sampling_offsets = nn.Linear(embed_dim, num_heads * num_levels * num_points * 2)
         self.attention_weights = nn.Linear(embed_dim, num_heads * num_levels * num_points)
         self.value_proj = nn.Linear(embed_dim, embed_dim)
@@ -153,19 +153,19 @@ class MultiScaleDeformableAttention(nn.Module):
         # the padding mask inside the kernel costs 4 byte loads per sample: cheaper than a fill pass over the projected
         # value for the decoder's few hundred queries, dearer for the encoder's Nq == S (measured: +32 us vs -21 us per call)
         mask_in_kernel = fused and key_padding_mask is not None and query.shape[1] * 4 <= value.shape[1]
-        _force = os.environ.get("RDETR_MASK_IN_KERNEL")          # A/B aid: "always" / "never"
+        _force = self.options.mask_in_kernel                     # A/B aid: "always" / "never"
         if _force and fused and key_padding_mask is not None:
             mask_in_kernel = _force == "always"
         # encoder shape (queries = the pyramid's own pixels) in bf16: the gather runs on a head-major value [B,H,S,D] (contiguous
         # head planes: 137 -> 115 us at BASELINE.json configs[1]), any level count; the padding zero-fill is
         # folded into the producer of that layout (no fill pass of its own)
         head_major = (fused and value.dtype == torch.bfloat16 and query.shape[1] == value.shape[1]
-                      and value.shape[1] >= 4096 and os.environ.get("RDETR_VALUE_HEAD_MAJOR", "1") != "0")
+                      and value.shape[1] >= 4096 and self.options.value_head_major)
         # ... written by the value projection itself where the hand-written projection kernel applies (csrc/linear.hip)
-        proj_hm = (head_major and os.environ.get("RDETR_VALUE_PROJ_HM", "1") != "0" and self.value_proj.bias is not None
+        proj_hm = (head_major and self.options.value_proj_hm and self.value_proj.bias is not None
                    and self.value_proj.bias.dtype == torch.bfloat16 and ops.linear_k256_supported(value, self.value_proj.weight))
         v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not (mask_in_kernel or head_major),
-                                              merged=fused and os.environ.get("RDETR_MERGED_PROJ", "1") != "0",
+                                              merged=fused and self.options.merged_proj,
                                               want_value=not proj_hm)
         vdt = value.dtype if proj_hm else v.dtype
         core_dtype = vdt if vdt in (torch.float32, torch.bfloat16) else torch.float32
@@ -202,7 +202,7 @@ class MultiScaleDeformableAttention(nn.Module):
             return self.output_proj(core)
         residual, norm = post_norm
         if (core.is_cuda and not torch.is_grad_enabled() and core.numel() // core.shape[-1] >= 16384
-                and os.environ.get("RDETR_PROJ_LN", "1") != "0" and norm.weight is not None and norm.bias is not None
+                and self.options.proj_ln and norm.weight is not None and norm.bias is not None
                 and ops.linear_ln_k256_supported(core, self.output_proj.weight, residual)):
             return ops.linear_ln_k256(core, self.output_proj.weight, self.output_proj.bias, residual, norm.weight, norm.bias, norm.eps)
         out = self.output_proj(core)

@@ -72,8 +72,35 @@ def check_levels(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, 
 
 
 VALUE_BSHD, VALUE_BHSD = 0, 1                     # include/relation_detr_amd.h: RDETR_VALUE_*
-MSDA_AUTO, MSDA_DIRECT, MSDA_WINDOW = 0, 1, 2     # RDETR_MSDA_*
-_ALGO = {"auto": MSDA_AUTO, "direct": MSDA_DIRECT, "window": MSDA_WINDOW}
+MSDA_AUTO, MSDA_DIRECT, MSDA_WINDOW, MSDA_AUTO_PACKED = 0, 1, 2, 3     # RDETR_MSDA_*
+
+
+def levels_window_ok(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, num_value: int) -> bool:
+    """Precondition of the LDS-window kernel (include/relation_detr_amd.h, RDETR_MSDA_WINDOW): the levels tile [0, S) exactly
+    -- cumulative starts, sum(h*w) == S -- and none outgrows level 0.  From the cached host copy of the table, through the
+    library's own host helper (one definition of the rule)."""
+    import ctypes
+    shapes, starts = host_levels(spatial_shapes, level_start_index)
+    n = len(shapes)
+    hs = (ctypes.c_int64 * (2 * n))(*[v for hw in shapes for v in hw])
+    st = (ctypes.c_int64 * n)(*starts)
+    return bool(_lib.load().rdetr_msda_levels_window_ok(hs, st, n, num_value))
+
+
+def _msda_algo(algo: str, spatial_shapes, level_start_index, num_value: int) -> int:
+    """'auto' may take the window kernel only for a level table that meets its precondition; an explicit 'window' on one
+    that does not is refused (it would leave output rows unwritten)."""
+    if algo == "direct":
+        return MSDA_DIRECT
+    ok = levels_window_ok(spatial_shapes, level_start_index, num_value)
+    if algo == "window":
+        if not ok:
+            raise _lib.RdetrError("algo='window' needs levels that tile [0, S) exactly (cumulative level_start_index, "
+                                  "sum(h*w) == S, no level larger than level 0)")
+        return MSDA_WINDOW
+    if algo != "auto":
+        raise ValueError("algo must be 'auto', 'direct' or 'window'")
+    return MSDA_AUTO_PACKED if ok else MSDA_DIRECT
 
 
 def _value_dims(value: torch.Tensor, layout: str):
@@ -106,29 +133,27 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_loc")
     if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
         raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
-    if algo not in _ALGO:
+    if algo not in ("auto", "direct", "window"):
         raise ValueError("algo must be 'auto', 'direct' or 'window'")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
-    if value.dtype == torch.bfloat16 and (value_layout != "bshd" or algo != "auto"):
+    if value.dtype == torch.bfloat16:
         st = lib.rdetr_msda_forward_opt_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD,
                                              spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-                                             attn_weight.data_ptr(), B, S, H, D, L, Nq, P, _ALGO[algo], out.data_ptr(),
+                                             attn_weight.data_ptr(), B, S, H, D, L, Nq, P,
+                                             _msda_algo(algo, spatial_shapes, level_start_index, S), out.data_ptr(),
                                              _stream_ptr(value))
         _lib.check(st, "rdetr_msda_forward_opt_bf16")
         return out
     if value_layout != "bshd" or algo != "auto":
         raise _lib.RdetrError("value_layout / algo options exist for bfloat16 value only")
-    if value.dtype == torch.float32:
-        fn = lib.rdetr_msda_forward_f32
-    elif value.dtype == torch.bfloat16:
-        fn = lib.rdetr_msda_forward_bf16
-    else:
+    if value.dtype != torch.float32:
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
-    st = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-            attn_weight.data_ptr(), B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
-    _lib.check(st, "rdetr_msda_forward")
+    st = lib.rdetr_msda_forward_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                    sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, H, D, L, Nq, P, out.data_ptr(),
+                                    _stream_ptr(value))
+    _lib.check(st, "rdetr_msda_forward_f32")
     return out
 
 
@@ -205,7 +230,7 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         raise _lib.RdetrError("sampling_offsets / attn_logits must have value's dtype, reference_points float32")
     if spatial_shapes.shape[0] != L:
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_offsets")
-    if algo not in _ALGO:
+    if algo not in ("auto", "direct", "window"):
         raise ValueError("algo must be 'auto', 'direct' or 'window'")
     if value.dtype not in (torch.float32, torch.bfloat16):
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
@@ -225,7 +250,8 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         st = lib.rdetr_msda_forward_fused_opt_bf16(
             value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), sampling_offsets.data_ptr(), ld_off, attn_logits.data_ptr(), ld_lg,
-            reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P, _ALGO[algo], out.data_ptr(), _stream_ptr(value))
+            reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P,
+            _msda_algo(algo, spatial_shapes, level_start_index, S), out.data_ptr(), _stream_ptr(value))
         _lib.check(st, "rdetr_msda_forward_fused_opt_bf16")
         return out
     if ld_off or ld_lg or mask_ptr is not None:

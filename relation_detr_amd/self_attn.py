@@ -95,10 +95,17 @@ class RelationSelfAttention(nn.Module):
             ctx = ops.relation_attention(q, k, v, H, None if attn_mask is None or is_bool else attn_mask.float(),
                                          attn_mask if is_bool else None, 1.0 / math.sqrt(d))
             return self.out_proj(ctx), None
-        q = q.view(B, N, H, d).transpose(1, 2)
-        k = k.view(B, M, H, d).transpose(1, 2)
-        v = v.view(B, M, H, d).transpose(1, 2)
-        scores = torch.matmul(q * (1.0 / math.sqrt(d)), k.transpose(-1, -2)).float().reshape(B * H, N, M).contiguous()
+        # The library's batched GEMMs get DENSE per-head operands [B, H, N, d].  As views of the packed projections (q / k:
+        # column slices with row stride 2C, heads interleaved inside a row) the batch of one image folds into a strided-
+        # batched GEMM with batch stride d and leading dimension 2C, i.e. matrices that OVERLAP in memory -- legal for the
+        # GEMM itself, but PyTorch's TunableOp sizes its scratch copy of such an operand as max(stride * batch, rows * cols
+        # * batch) elements (ATen/cuda/tunable/GemmCommon.h, GemmStridedBatchedParams::GetSizeA: the leading dimension is not
+        # in the formula), half of what a candidate kernel then reads with lda = 2C: the out-of-bounds read behind round 2's
+        # "Memory access fault" while tuning the fp32 decoder.  One copy of N x C elements per operand.
+        q = (q * (1.0 / math.sqrt(d))).view(B, N, H, d).transpose(1, 2).contiguous()
+        k = k.view(B, M, H, d).transpose(1, 2).contiguous()
+        v = v.view(B, M, H, d).transpose(1, 2).contiguous()
+        scores = torch.matmul(q, k.transpose(-1, -2)).float().reshape(B * H, N, M).contiguous()
         bias = mask = None
         if attn_mask is not None:
             if attn_mask.dtype == torch.bool:

@@ -17,7 +17,6 @@ time the same glue with the CPU oracle's operators as the host baseline; the def
 from __future__ import annotations
 
 import math
-import os
 from typing import List, Sequence
 
 import torch
@@ -25,6 +24,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import ops
+from . import options as _options
 from .ms_deform_attn import MultiScaleDeformableAttention
 from .relation import PositionRelationEmbedding
 from .self_attn import RelationSelfAttention
@@ -76,12 +76,12 @@ def add_norm(norm: nn.LayerNorm, x: Tensor, residual: Tensor = None, out: Tensor
 _K256_MIN_ROWS = 16384          # below this the library GEMM's shorter fixed cost wins (csrc/linear.hip)
 
 
-def linear_relu(linear: nn.Linear, x: Tensor) -> Tensor:
+def linear_relu(linear: nn.Linear, x: Tensor, opts: "_options.Options" = None) -> Tensor:
     """relu(linear(x)); on a device the ReLU runs in the GEMM's epilogue (hipBLASLt) instead of a pass of its own over
     the [.., d_ffn] activations."""
     if x.is_cuda and linear.bias is not None and not (torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)):
         rows = x.numel() // x.shape[-1]
-        if (rows >= _K256_MIN_ROWS and linear.out_features >= 1024 and os.environ.get("RDETR_LINEAR_K256", "0") == "1"
+        if (rows >= _K256_MIN_ROWS and linear.out_features >= 1024 and (opts or _options.get()).linear_k256
                 and not torch.is_grad_enabled() and ops.linear_k256_supported(x, linear.weight)):
             # opt-in: hand-written MFMA kernel for the tall K = 256, wide-output linear1 of the encoder FFN.  Alone it beats the
             # library GEMM (72 vs 87 us at 44,646 rows), inside the two-group replay it does not (-1 %: its persistent
@@ -92,18 +92,18 @@ def linear_relu(linear: nn.Linear, x: Tensor) -> Tensor:
     return F.relu(linear(x))
 
 
-def _fused_ffn_applies(linear1: nn.Linear, linear2: nn.Linear, x: Tensor) -> bool:
+def _fused_ffn_applies(linear1: nn.Linear, linear2: nn.Linear, x: Tensor, opts: "_options.Options" = None) -> bool:
     return (x.is_cuda and not torch.is_grad_enabled() and x.numel() // x.shape[-1] >= _K256_MIN_ROWS
-            and linear1.bias is not None and linear2.bias is not None and os.environ.get("RDETR_FFN_FUSED", "1") != "0"
+            and linear1.bias is not None and linear2.bias is not None and (opts or _options.get()).ffn_fused
             and ops.ffn_k256_supported(x, linear1.weight, linear2.weight))
 
 
-def feed_forward(linear1: nn.Linear, linear2: nn.Linear, x: Tensor) -> Tensor:
+def feed_forward(linear1: nn.Linear, linear2: nn.Linear, x: Tensor, opts: "_options.Options" = None) -> Tensor:
     """linear2(relu(linear1(x))) (relation_transformer.py:226-233, 272-275).  Tall bf16 inputs at inference go through the fused
-    kernel (csrc/ffn.hip: the [rows, d_ffn] activations never reach HBM); RDETR_FFN_FUSED=0 keeps the two library GEMMs."""
-    if _fused_ffn_applies(linear1, linear2, x):
+    kernel (csrc/ffn.hip: the [rows, d_ffn] activations never reach HBM); options.ffn_fused = False keeps the two library GEMMs."""
+    if _fused_ffn_applies(linear1, linear2, x, opts):
         return ops.ffn_k256(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias)
-    return linear2(linear_relu(linear1, x))
+    return linear2(linear_relu(linear1, x, opts))
 
 
 class MLP(nn.Module):
@@ -113,6 +113,7 @@ class MLP(nn.Module):
         super().__init__()
         dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
         self.num_layers = num_layers
+        self.options = _options.get()
         self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
         for layer in self.layers:
             nn.init.xavier_uniform_(layer.weight)
@@ -120,7 +121,7 @@ class MLP(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         for i, layer in enumerate(self.layers):
-            x = linear_relu(layer, x) if i + 1 < self.num_layers else layer(x)
+            x = linear_relu(layer, x, self.options) if i + 1 < self.num_layers else layer(x)
         return x
 
 
@@ -128,6 +129,7 @@ class RelationTransformerEncoderLayer(nn.Module):
     def __init__(self, embed_dim=256, d_ffn=1024, n_heads=8, n_levels=4, n_points=4, msda_cls=MultiScaleDeformableAttention):
         super().__init__()
         self.embed_dim = embed_dim
+        self.options = _options.get()
         self.self_attn = msda_cls(embed_dim, n_levels, n_heads, n_points)
         self.norm1 = nn.LayerNorm(embed_dim)
         self.linear1 = nn.Linear(embed_dim, d_ffn)
@@ -152,13 +154,13 @@ class RelationTransformerEncoderLayer(nn.Module):
                                   value=query, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                   key_padding_mask=key_padding_mask)
             query = add_norm(self.norm1, query, attn)
-        if _fused_ffn_applies(self.linear1, self.linear2, query) and os.environ.get("RDETR_FFN_LN", "0") == "1":
+        if self.options.ffn_ln and _fused_ffn_applies(self.linear1, self.linear2, query, self.options):
             # opt-in: feed-forward block, residual, LayerNorm (and the next layer's query + pos) in ONE kernel (csrc/ffn.hip).
             # Correct (tests/test_gpu_glue.py) but 3-6 % slower in the stack than fused FFN + the add+LayerNorm kernel: the
             # epilogue runs with the matrix pipe idle, the separate kernel overlaps the other image group
             return ops.ffn_ln_k256(query, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                                    self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, pos=next_pos)
-        ffn = feed_forward(self.linear1, self.linear2, query)
+        ffn = feed_forward(self.linear1, self.linear2, query, self.options)
         if next_pos is not None:
             return ops.add_layer_norm(query, ffn, self.norm2.weight, self.norm2.bias, self.norm2.eps, out=out, pos=next_pos)
         return add_norm(self.norm2, query, ffn, out=out)
@@ -172,6 +174,7 @@ class RelationTransformerEncoder(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.num_layers = len(self.layers)
         self.embed_dim = self.layers[0].embed_dim
+        self.options = _options.get()
         d = self.embed_dim
         self.memory_fusion = nn.Sequential(nn.Linear((self.num_layers + 1) * d, d), nn.ReLU(inplace=True), nn.Linear(d, d),
                                            nn.LayerNorm(d))
@@ -192,7 +195,7 @@ class RelationTransformerEncoder(nn.Module):
                 stacked[..., :d].copy_(query)
             query = stacked[..., :d]
             fuse_pos = (query_pos is not None and query.dtype in (torch.float32, torch.bfloat16)
-                        and os.environ.get("RDETR_LN_POS", "1") != "0")          # =0: separate add (A/B)
+                        and self.options.ln_pos)                                # False: separate add (A/B)
             qpp = None
             for i, layer in enumerate(self.layers):
                 last = i + 1 == self.num_layers
@@ -200,12 +203,12 @@ class RelationTransformerEncoder(nn.Module):
                             out=stacked[..., (i + 1) * d:(i + 2) * d], query_plus_pos=qpp,
                             next_pos=query_pos if fuse_pos and not last else None)
                 query, qpp = res if isinstance(res, tuple) else (res, None)
-            return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], stacked)))
+            return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], stacked, self.options)))
         outs = [query]
         for layer in self.layers:
             query = layer(query, query_pos, reference_points, spatial_shapes, level_start_index, query_key_padding_mask)
             outs.append(query)
-        return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], torch.cat(outs, -1))))
+        return add_norm(fuse[3], fuse[2](linear_relu(fuse[0], torch.cat(outs, -1), self.options)))
 
 
 class RelationTransformerDecoderLayer(nn.Module):
@@ -213,6 +216,7 @@ class RelationTransformerDecoderLayer(nn.Module):
                  msda_cls=MultiScaleDeformableAttention, self_attn_cls=RelationSelfAttention):
         super().__init__()
         self.embed_dim, self.num_heads = embed_dim, n_heads
+        self.options = _options.get()
         self.cross_attn = msda_cls(embed_dim, n_levels, n_heads, n_points)
         self.norm1 = nn.LayerNorm(embed_dim)
         self.self_attn = self_attn_cls(embed_dim, n_heads, dropout=0.0, batch_first=True)
@@ -229,7 +233,7 @@ class RelationTransformerDecoderLayer(nn.Module):
         qp = query + query_pos if query_plus_pos is None else query_plus_pos
         attn = self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask, need_weights=False)[0]
         if (query.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16)
-                and query_pos.dtype == query.dtype and query_pos.shape == query.shape and os.environ.get("RDETR_DECODER_LN_POS", "1") != "0"):
+                and query_pos.dtype == query.dtype and query_pos.shape == query.shape and self.options.decoder_ln_pos):
             # inference: norm2 and the cross-attention's `query + query_pos` from one pass (csrc/layernorm.hip)
             query, cross_q = ops.add_layer_norm(attn, query, self.norm2.weight, self.norm2.bias, self.norm2.eps, pos=query_pos)
         else:
@@ -239,7 +243,7 @@ class RelationTransformerDecoderLayer(nn.Module):
                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                 key_padding_mask=key_padding_mask)
         query = add_norm(self.norm1, query, cross)
-        return add_norm(self.norm3, query, feed_forward(self.linear1, self.linear2, query))
+        return add_norm(self.norm3, query, feed_forward(self.linear1, self.linear2, query, self.options))
 
 
 class RelationTransformerDecoder(nn.Module):
@@ -251,6 +255,7 @@ class RelationTransformerDecoder(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.num_layers = len(self.layers)
         self.embed_dim, self.num_heads = self.layers[0].embed_dim, self.layers[0].num_heads
+        self.options = _options.get()
         d = self.embed_dim
         self.ref_point_head = MLP(2 * d, d, d, 2)
         self.query_scale = MLP(d, d, d, 2)
@@ -275,7 +280,7 @@ class RelationTransformerDecoder(nn.Module):
         for idx, layer in enumerate(self.layers):
             if (reference_points.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16)
                     and reference_points.dtype == torch.float32 and valid_ratios.dtype == torch.float32
-                    and os.environ.get("RDETR_DECODER_ENTRY", "1") != "0"):
+                    and self.options.decoder_entry):
                 # inference: the scaling by the valid ratios, the level-0 slice and its sine embedding in one launch (csrc/glue.hip)
                 ref_in, emb = ops.decoder_reference(reference_points.detach(), valid_ratios, self.embed_dim // 2, dtype=query.dtype)
             else:
@@ -287,7 +292,7 @@ class RelationTransformerDecoder(nn.Module):
             qpp = None
             if idx != 0:
                 if query.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16) \
-                        and query_pos.dtype == query.dtype and os.environ.get("RDETR_DECODER_ENTRY", "1") != "0":
+                        and query_pos.dtype == query.dtype and self.options.decoder_entry:
                     query_pos, qpp = ops.scaled_pos(query_pos, self.query_scale(query), query)      # the product and query + product
                 else:
                     query_pos = query_pos * self.query_scale(query)
@@ -301,7 +306,7 @@ class RelationTransformerDecoder(nn.Module):
             # bf16 inference: the box head on `normed` (this layer's boxes) and on `query` (the next reference points) with both
             # refinements as ONE kernel (csrc/mlp.hip) instead of 6 GEMMs + 2 launches of the decoder's dependency chain
             fused_box = (query.is_cuda and not torch.is_grad_enabled() and reference_points.dtype == torch.float32
-                         and os.environ.get("RDETR_BOX_HEAD", "1") != "0" and ops.box_head_k256_supported(normed, self.bbox_head[idx].layers))
+                         and self.options.box_head and ops.box_head_k256_supported(normed, self.bbox_head[idx].layers))
             if fused_box:
                 res = ops.box_head_k256(normed, None if last else query, self.bbox_head[idx].layers, reference_points.detach())
                 out_coord, next_reference = (res, None) if last else res
@@ -316,7 +321,7 @@ class RelationTransformerDecoder(nn.Module):
                 src_boxes = tgt_boxes if idx >= 1 else reference_points
                 tgt_boxes = out_coord
                 if (query.is_cuda and query.dtype == torch.bfloat16 and not torch.is_grad_enabled()
-                        and hasattr(self.position_relation_embedding, "deferred") and os.environ.get("RDETR_REL_FUSED", "1") != "0"):
+                        and hasattr(self.position_relation_embedding, "deferred") and self.options.rel_fused):
                     # bf16 inference: hand the next layer the recipe; its attention kernel generates the bias (csrc/attn_rel.hip)
                     pos_relation = self.position_relation_embedding.deferred(src_boxes, tgt_boxes, attn_mask)
                 else:
@@ -338,6 +343,7 @@ class RelationTransformer(nn.Module):
         self.embed_dim, self.num_feature_levels = d, num_feature_levels
         self.two_stage_num_proposals, self.num_classes = two_stage_num_proposals, num_classes
         self.hybrid_num_proposals = hybrid_num_proposals
+        self.options = _options.get()
         self.level_embeds = nn.Parameter(torch.empty(num_feature_levels, d))
         self.enc_output = nn.Linear(d, d)
         self.enc_output_norm = nn.LayerNorm(d)
@@ -448,7 +454,7 @@ class RelationTransformer(nn.Module):
         else:
             feat = self.flatten_levels(multi_level_feats)
             pos = self.flatten_levels([p + e.view(1, -1, 1, 1) for p, e in zip(multi_level_pos_embeds, self.level_embeds)])
-        fast = self._fast(multi_level_feats[0]) and len(multi_level_masks) <= 8 and os.environ.get("RDETR_PYRAMID_POINTS", "1") != "0"
+        fast = self._fast(multi_level_feats[0]) and len(multi_level_masks) <= 8 and self.options.pyramid_points
         if fast:
             # inference: valid ratios, reference points, proposal logits and the validity factor in two launches (csrc/glue.hip)
             # instead of ~40 small ones
@@ -497,11 +503,11 @@ class RelationTransformer(nn.Module):
             # inference: the box head is per token, so it runs on the k selected tokens instead of all S (the reference computes all
             # boxes and gathers, :88-96 -- same values, 3 GEMMs on 900 rows instead of 22,323 per image)
             scores = ops.row_max(logits)
-            use_own = os.environ.get("RDETR_TOPK", "1") != "0" and ops.topk_supported(scores, k)
+            use_own = self.options.topk and ops.topk_supported(scores, k)
             top = (ops.topk(scores, k)[1] if use_own else torch.topk(scores, k, dim=1)[1]).unsqueeze(-1)
             sel = out_memory.gather(1, top.expand(-1, -1, out_memory.shape[-1]))
             prop = out_proposals.gather(1, top.expand(-1, -1, 4))
-            if os.environ.get("RDETR_BOX_HEAD", "1") != "0" and prop.dtype == torch.float32 and ops.box_head_k256_supported(sel, bbox_head.layers):
+            if self.options.box_head and prop.dtype == torch.float32 and ops.box_head_k256_supported(sel, bbox_head.layers):
                 boxes = ops.box_head_k256(sel, None, bbox_head.layers, prop, reference_is_logit=True)      # 3 GEMMs + add + sigmoid
             else:
                 boxes = (bbox_head(sel).float() + prop).sigmoid()
@@ -526,20 +532,21 @@ def build_relation_transformer(num_classes=91, embed_dim=256, num_heads=8, d_ffn
 
 
 @torch.no_grad()
-def select_detections(logits: Tensor, boxes: Tensor, image_sizes: Tensor, k: int = 300) -> Tensor:
+def select_detections(logits: Tensor, boxes: Tensor, image_sizes: Tensor, k: int = 300, opts: "_options.Options" = None) -> Tensor:
     """Fixed-shape form of PostProcess (models/bricks/post_process.py:21-44, default config: 300 detections,
     no NMS / score filter): sigmoid -> top-k over N*C -> cxcywh to xyxy -> scale to pixels.
     logits [B,N,C], boxes [B,N,4] cxcywh in [0,1], image_sizes [B,2] (h,w) -> [B,k,6] = (x1,y1,x2,y2,score,label),
     the tensor `dist.gather_detections` all-gathers."""
     B, N, C = logits.shape
+    opts = opts or _options.get()
     prob = logits.sigmoid().view(B, -1)
-    if logits.is_cuda and os.environ.get("RDETR_TOPK", "1") != "0" and ops.topk_supported(prob, k):
+    if logits.is_cuda and opts.topk and ops.topk_supported(prob, k):
         score, idx = ops.topk(prob, k)                  # equal scores by ascending index (csrc/topk.hip); torch: unspecified
         score = score.to(prob.dtype)
     else:
         score, idx = torch.topk(prob, k, dim=1)
     if (logits.is_cuda and score.dtype == torch.float32 and boxes.dtype == torch.float32 and image_sizes.dtype == torch.int64
-            and os.environ.get("RDETR_DETECTIONS_KERNEL", "1") != "0"):
+            and opts.detections_kernel):
         return ops.detections_from_topk(score, idx, boxes, image_sizes, C)       # the rest of this function in one launch
     box_idx = torch.div(idx, C, rounding_mode="trunc")
     label = idx % C

@@ -84,6 +84,19 @@ def test_bench_launcher_two_ranks_dry_run():
     assert res["metric"].startswith("images/sec @ 800") and "300 queries" in res["metric"]
 
 
+def test_bench_launcher_ends_all_ranks_when_one_dies():
+    """A rank that exits non-zero before its first collective must not leave the launcher waiting on the other rank's
+    collective timeout (poll all children, end the rest on the first failure, return non-zero) -- and the
+    rendezvous is a file store in a private directory, so no TCP port is chosen and raced for."""
+    import time
+    t0 = time.monotonic()
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--steps", "50", "--warmup", "1", "--batch", "4"],
+                                {"RDETR_BENCH_DRY_FAIL_RANK": "1"}, timeout=120)
+    assert rc == 1 and not lines, (rc, lines, err[-1000:])
+    assert "ranks failed" in err and "(1, 3)" in err
+    assert time.monotonic() - t0 < 90                   # not the ~10-minute collective timeout
+
+
 def test_bench_refuses_world_size_mismatch():
     """--gpus N must agree with the ranks actually launched: a silent 1-GPU run labelled otherwise is refused."""
     rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],

@@ -127,7 +127,7 @@ def test_unsupported_configurations_are_refused():
 
 
 def test_decoder_takes_the_generated_bias_and_agrees_with_the_materialised_route(monkeypatch):
-    """RelationTransformerDecoder in bf16 eval hands its layers a DeferredRelationBias; RDETR_REL_FUSED=0 keeps the reference's
+    """RelationTransformerDecoder in bf16 eval hands its layers a DeferredRelationBias; options.rel_fused = False keeps the reference's
     sequence (bias tensor -> masked_fill_ -> attn_mask).  Same boxes, same weights: the decoder outputs agree to bf16 noise."""
     from relation_detr_amd import ops
     from relation_detr_amd.transformer import build_relation_transformer
@@ -144,7 +144,8 @@ def test_decoder_takes_the_generated_bias_and_agrees_with_the_materialised_route
     with torch.no_grad():
         fused = net(feats, masks, pos)
         assert len(calls) == 2                                                   # layers 1 and 2 (layer 0 has no bias)
-        monkeypatch.setenv("RDETR_REL_FUSED", "0")
+        from relation_detr_amd import options
+        options.apply(net, rel_fused=False)
         plain = net(feats, masks, pos)
         assert len(calls) == 2
     for a, b_ in zip(fused[:2], plain[:2]):

@@ -23,17 +23,9 @@ T = torch.from_numpy
 
 @pytest.fixture(scope="module")
 def bench():
-    # bench.py switches PyTorch's TunableOp on at import (GEMM tuning during ITS warm-up); tests compare numerics and must not
-    # try library-kernel candidates: a tuning run over the fp32 shapes of this file ended in a GPU memory fault inside a
-    # candidate GEMM (gpurun_out/r02/fullsize_1.log) -- the same forward is clean with tuning off (diag_full*.log)
-    import os
-    os.environ["RDETR_BENCH_TUNABLEOP"] = "0"
-    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "0"
+    # GEMM tuning (PyTorch's TunableOp) is opt-in in bench.py and off here: these tests compare numerics, and the library kernel a
+    # tuner picks may differ from run to run.  test_fp32_self_attention_under_gemm_tuning below switches it on on purpose.
     import bench as b
-    try:
-        torch.cuda.tunable.enable(False)
-    except Exception:
-        pass
     return b
 
 
@@ -42,9 +34,12 @@ def _forward(net, feats, masks, pos):
         return net(feats, masks, pos)
 
 
-@pytest.mark.parametrize("queries", [900, 300])
-def test_fp32_stack_matches_cpu_oracle_full_size(bench, queries):
-    """Encoder + two-stage scores end to end, then the decoder on IDENTICAL inputs.  The two-stage top-k over 22,323 nearly
+@pytest.mark.parametrize("config,queries", [("r50", 900), ("r50", 300), ("focalnet", 900)])
+def test_fp32_stack_matches_cpu_oracle_full_size(bench, config, queries):
+    """BASELINE.json configs[1] (R50, 4 levels, S = 22,323) and configs[4] (FocalNet-L, 5 levels (304,504) ... (19,32),
+    S = 204,098: pyramid_points, nchw_to_tokens, the memory-fusion buffer, the L = 5 gather and the 900-query decoder with
+    5-level cross-attention) on one full-size padded image.
+    Encoder + two-stage scores end to end, then the decoder on IDENTICAL inputs.  The two-stage top-k over 22,323 nearly
     equal scores (random-init class head: prior bias + O(1e-2)) is decided at the 1e-6 level, where fp32 summation order
     already differs between ATen's CPU kernels and the GPU's: a single swapped proposal reorders the queries.  So the
     continuous quantities are compared where they are continuous -- encoder memory and the full [S, C] score map -- the
@@ -52,13 +47,16 @@ def test_fp32_stack_matches_cpu_oracle_full_size(bench, queries):
     bias, box refinement) is run on both sides from the GPU's own proposals."""
     from oracle.cpu_modules import OracleMSDA, OracleRelation, OracleSelfAttention
     torch.set_num_threads(16)
-    cpu_net = bench.build_network(queries, 0, msda_cls=OracleMSDA, self_attn_cls=OracleSelfAttention, relation_cls=OracleRelation)
-    gpu_net = bench.build_network(queries, 0).to(DEV)
+    cfg = bench.CONFIGS[config]
+    nlev = len(cfg["shapes"])
+    cpu_net = bench.build_network(queries, 0, num_levels=nlev, msda_cls=OracleMSDA, self_attn_cls=OracleSelfAttention,
+                                  relation_cls=OracleRelation)
+    gpu_net = bench.build_network(queries, 0, num_levels=nlev).to(DEV)
     assert all(torch.equal(a, b.cpu()) for a, b in zip(cpu_net.state_dict().values(), gpu_net.state_dict().values()))
-    feats, masks, pos = bench.build_pyramid(1, "cpu", 7)
-    masks[0][0, :, 150:] = True                              # right padding: valid_ratios < 1, padded value rows
-    for l in range(1, 4):
-        masks[l][0, :, masks[l].shape[2] * 150 // 168:] = True
+    feats, masks, pos = bench.build_pyramid(1, "cpu", 7, shapes=cfg["shapes"])
+    for l in range(nlev):                                    # right padding: valid_ratios < 1, padded value rows
+        w = masks[l].shape[2]
+        masks[l][0, :, max(1, w * 150 // 168):] = True
     seen = {}
     for tag, net in (("cpu", cpu_net), ("gpu", gpu_net)):
         net.encoder.register_forward_hook(lambda m, i, o, tag=tag: seen.__setitem__(tag + "_memory", o.detach().float().cpu()))
@@ -84,26 +82,34 @@ def test_fp32_stack_matches_cpu_oracle_full_size(bench, queries):
         c_cls, c_box = cpu_net.decoder(query=cpu_net.tgt_embed.weight.expand(1, -1, -1), value=memory, key_padding_mask=mask.cpu(),
                                        reference_points=ref.cpu(), spatial_shapes=geo["shapes"].cpu(),
                                        level_start_index=geo["start"].cpu(), valid_ratios=vr.cpu())
-    assert g_cls.shape == (6, 1, queries, 91)
+    assert g_cls.shape == (6, 1, queries, 91) and geo["shapes"].shape[0] == nlev
     np.testing.assert_allclose(g_cls.float().cpu().numpy(), c_cls.numpy(), rtol=0, atol=5e-4)
     np.testing.assert_allclose(g_box.float().cpu().numpy(), c_box.numpy(), rtol=0, atol=5e-4)
     # and the harness's own decoder outputs are the ones just checked (same proposals in, same kernels)
     np.testing.assert_allclose(got[0].float().cpu().numpy(), g_cls.float().cpu().numpy(), rtol=0, atol=1e-5)
 
 
+CLASS_SCALE = 32.0          # class-head weight scale of the detection-level comparisons (bench.build_network): logits spread
+                            # over ~+-1.5 around the prior instead of ~+-0.05, i.e. far above bf16 resolution (ulp 0.03 at 4.6)
+
+
 def test_bf16_two_group_replay_vs_fp32_full_size(bench):
-    """bench.py's default launch against the fp32 harness.  With random-init weights the class logits sit within a few 1e-2
-    of the prior bias, so WHICH 900 of the 22,323 proposals make the two-stage cut is decided below bf16 resolution: the
-    query sets differ, and a detection-level match is only meaningful as the statistic bench.py reports.  The continuous part
-    of the path (the encoder, whose six MSDA / fused FFN / linear+LayerNorm layers are the benched kernels) is held to a
-    relative L2 bound; the detections to the measured level."""
+    """bench.py's default launch against the fp32 harness, on a network whose class scores are SEPARATED (CLASS_SCALE): with
+    the reference's init every class logit sits within a few 1e-2 of the prior bias, below bf16 resolution, and a detection
+    match between the two arithmetic routes says nothing.
+      * encoder memory bf16 vs fp32: relative L2 < 2^-5; replay vs eager: bit-identical detections (own total-order top-k,
+        csrc/topk.hip -- nothing on the path is order-dependent any more);
+      * detections bf16 vs fp32 at IoU 0.9, same label: the bound below.  What keeps it from 1.0 is structural, not noise in a
+        kernel: the two-stage cut ranks 22,323 continuous scores and hands query slot r the r-th best proposal; bf16 noise of
+        ~1 % of the score spread is ~20 rank spacings at the cut, so a few per cent of the proposals change slots or drop out.
+        The decoder itself is bounded on IDENTICAL proposals by test_bf16_decoder_on_identical_proposals_full_size."""
     from relation_detr_amd.graph import GraphedCall, ImageGroups
     from relation_detr_amd.transformer import select_detections
     B, L = 4, 4
     feats, masks, pos = bench.build_pyramid(B, DEV, seed=1000, dtype=torch.float32)
     sizes = torch.tensor([[800, 1333]] * B, device=DEV)
-    net32 = bench.build_network(900, 0).to(DEV)
-    net16 = bench.build_network(900, 0).to(DEV).to(torch.bfloat16)
+    net32 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV)
+    net16 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV).to(torch.bfloat16)
     mem = {"fp32": [], "bf16": []}                       # per image group, in launch order
     net32.encoder.register_forward_hook(lambda m, i, o: mem["fp32"].append(o.detach().float().clone()))
     net16.encoder.register_forward_hook(lambda m, i, o: mem["bf16"].append(o.detach().float().clone()))
@@ -128,23 +134,114 @@ def test_bf16_two_group_replay_vs_fp32_full_size(bench):
     run = GraphedCall(ImageGroups(make(net16), 2, device=DEV), in16)
     det16 = run(*in16).clone()
     torch.cuda.synchronize()
-    # replay vs eager: the same kernels of this library on the same inputs, but (a) the library GEMMs the heuristics pick under
-    # capture are not always the ones picked eagerly at these shapes (the encoder memory of the two runs differs by a few bf16
-    # ulps after six layers), and (b) the two-stage torch.topk runs over bf16 scores with many EXACT ties, whose order among
-    # equal scores is not reproducible from call to call; one swapped tie changes an image's query set and with it all of
-    # that image's detections (observed: 0, 1 or 2 of the 4 images differ between two runs).
-    # tests/test_gpu_glue.py::test_graph_replay_matches_eager holds replay == eager bit for bit, end to end, at a size where
-    # neither happens.
+    # replay vs eager: the same kernels on the same inputs.  The library GEMMs the heuristics pick under capture are not always
+    # the ones picked eagerly (a few bf16 ulps in the encoder memory after six layers); the two selections are rdetr_topk's
+    # total order (value, then index), so equal scores no longer reorder from call to call.
     m16_replay = torch.cat(mem["bf16"][-2:], 0)
     rel_replay = ((m16_replay - m16).norm() / m16.norm()).item()
     assert rel_replay < 2.0 ** -7, f"encoder memory replay vs eager: relative L2 {rel_replay:.5f}"
     same = bench.detection_drift(det16, eager16, iou_thr=0.9)
     print("replay vs eager:", same)
-    assert same["matched_frac"] >= 0.45, same
-    d = bench.detection_drift(det16, det32, iou_thr=0.5)
-    print("bf16 vs fp32 detections:", d, "encoder memory rel L2:", rel)
+    assert same["matched_frac"] >= 0.99, same
+    d9 = bench.detection_drift(det16, det32, iou_thr=0.9)
+    d5 = bench.detection_drift(det16, det32, iou_thr=0.5)
+    print("bf16 vs fp32 detections:", d9, d5, "encoder memory rel L2:", rel)
     assert torch.isfinite(det16).all() and det16.shape == (B, 300, 6)
-    assert d["matched_frac"] >= 0.25, d          # measured 0.4-0.6 (IoU 0.5, same label) on random-init weights; see docstring
+    assert d9["matched_frac"] >= BF16_MATCH_IOU90, d9
+    assert d5["matched_frac"] >= d9["matched_frac"]
+
+
+BF16_MATCH_IOU90 = 0.5       # calibrated on the GPU (tools/exp_separation.py): see the docstring above
+
+
+def test_bf16_decoder_on_identical_proposals_full_size(bench):
+    """The continuous bound the detection statistic cannot give: the bf16 decoder -- generated-bias
+    attention (csrc/attn_rel.hip), fused box head (csrc/mlp.hip), bf16 fused-producer MSDA cross-attention, decoder_reference,
+    scaled_pos, six layers in composition at 900 queries -- against the fp32 decoder on IDENTICAL inputs: the fp32 run's encoder
+    memory and its top-900 proposals, B = 2 with one padded image.  Mirrors the fp32-vs-CPU-oracle check above."""
+    B, L = 2, 4
+    feats, masks, pos = bench.build_pyramid(B, DEV, seed=77, dtype=torch.float32)
+    for l in range(L):
+        w = masks[l].shape[2]
+        masks[l][1, :, w * 150 // 168:] = True
+    net32 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV)
+    net16 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV).to(torch.bfloat16)
+    seen = {}
+    net32.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("memory", o.detach().clone()))
+    with torch.no_grad():
+        got = net32(feats, masks, pos)
+        geo, vr = net32.level_misc(masks)
+        mask = net32.flatten_levels(masks)
+        memory, ref = seen["memory"], got[3].float().detach()
+        kw = dict(key_padding_mask=mask, reference_points=ref, spatial_shapes=geo["shapes"], level_start_index=geo["start"],
+                  valid_ratios=vr)
+        c32, b32 = net32.decoder(query=net32.tgt_embed.weight.expand(B, -1, -1), value=memory, **kw)
+        c16, b16 = net16.decoder(query=net16.tgt_embed.weight.expand(B, -1, -1), value=memory.to(torch.bfloat16), **kw)
+    np.testing.assert_allclose(got[0].float().cpu().numpy(), c32.cpu().numpy(), rtol=0, atol=1e-5)   # same proposals in, same kernels
+    c32, b32, c16, b16 = c32.float(), b32.float(), c16.float(), b16.float()
+    assert torch.isfinite(c16).all() and torch.isfinite(b16).all()
+    spread = (c32 - c32.mean()).abs().max().item()               # logits: O(1-5) around the prior with CLASS_SCALE
+    dbox, dcls = (b16 - b32).abs(), (c16 - c32).abs()
+    print(f"bf16 decoder vs fp32 on identical proposals: boxes max {dbox.max().item():.4f} mean {dbox.mean().item():.5f}; "
+          f"logits max {dcls.max().item():.4f} mean {dcls.mean().item():.5f} (spread {spread:.2f}); per layer box max "
+          f"{[round(v, 4) for v in dbox.amax((1, 2, 3)).tolist()]} logit max {[round(v, 4) for v in dcls.amax((1, 2, 3)).tolist()]}")
+    assert dbox.max().item() <= 2e-2 and dbox.mean().item() <= 2e-3
+    assert dcls.max().item() <= 2.0 ** -3 * spread and dcls.mean().item() <= 2.0 ** -6 * spread
+
+
+def test_bf16_focalnet_5_level_stack_full_size(bench):
+    """BASELINE.json configs[4] per rank in bf16 (the route bench.py --config focalnet times): 5 levels, S = 204,098, 900
+    queries, B = 1 -- finite outputs of the right shape, and the encoder memory within 2^-5 relative L2 of the fp32 HIP run
+    on the same image (whose own parity against the CPU oracle is the focalnet case of the fp32 test above)."""
+    cfg = bench.CONFIGS["focalnet"]
+    L = len(cfg["shapes"])
+    feats, masks, pos = bench.build_pyramid(1, DEV, seed=5, dtype=torch.float32, shapes=cfg["shapes"])
+    for l in range(L):
+        h = masks[l].shape[1]
+        masks[l][0, max(1, h * 9 // 10):, :] = True            # bottom padding
+    net32 = bench.build_network(900, 0, num_levels=L).to(DEV)
+    net16 = bench.build_network(900, 0, num_levels=L).to(DEV).to(torch.bfloat16)
+    mem = {}
+    net32.encoder.register_forward_hook(lambda m, i, o: mem.__setitem__("fp32", o.detach().float().clone()))
+    net16.encoder.register_forward_hook(lambda m, i, o: mem.__setitem__("bf16", o.detach().float().clone()))
+    with torch.no_grad():
+        o32 = net32(feats, masks, pos)
+        o16 = net16([f.to(torch.bfloat16) for f in feats], masks, [p.to(torch.bfloat16) for p in pos])
+    torch.cuda.synchronize()
+    assert mem["fp32"].shape == (1, 204098, 256)
+    rel = ((mem["bf16"] - mem["fp32"]).norm() / mem["fp32"].norm()).item()
+    print("focalnet encoder memory bf16 vs fp32: relative L2", rel)
+    assert rel < 2.0 ** -5
+    assert o16[0].shape == (6, 1, 900, 91) and o16[1].shape == (6, 1, 900, 4) and o16[3].shape == (1, 900, 4)
+    assert all(torch.isfinite(t.float()).all() for t in o16[:4]) and all(torch.isfinite(t).all() for t in o32[:4])
+    assert ((o16[1].float() >= 0) & (o16[1].float() <= 1)).all()
+
+
+def test_fp32_self_attention_under_gemm_tuning():
+    """Round 2's GPU memory fault (gpurun_out/r02/fullsize_1.log) came from PyTorch's TunableOp tuning the fp32 decoder
+    self-attention of ONE image: q / k were column-slice views of the packed projection, which for B = 1 fold into a
+    strided-batched GEMM with batch stride 32 and leading dimension 512 -- overlapping matrices -- and TunableOp sizes its
+    scratch copy of such an operand without the leading dimension (GemmStridedBatchedParams::GetSizeA), so candidate kernels
+    read past its end.  RelationSelfAttention now hands the library dense per-head operands; this test runs exactly that
+    call (B = 1, N = 900, float bias) with tuning ON, once, and checks the result against the untuned run."""
+    from relation_detr_amd.self_attn import RelationSelfAttention
+    torch.manual_seed(3)
+    att = RelationSelfAttention(256, 8).to(DEV).eval()
+    x, v = torch.randn(1, 900, 256, device=DEV), torch.randn(1, 900, 256, device=DEV)
+    bias = torch.randn(8, 900, 900, device=DEV)
+    with torch.no_grad():
+        want = att(query=x, key=x, value=v, attn_mask=bias)[0].clone()
+        was_on, was_tuning = torch.cuda.tunable.is_enabled(), torch.cuda.tunable.tuning_is_enabled()
+        try:
+            torch.cuda.tunable.set_max_tuning_duration(30)
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(True)
+            got = att(query=x, key=x, value=v, attn_mask=bias)[0].clone()
+            torch.cuda.synchronize()
+        finally:
+            torch.cuda.tunable.tuning_enable(was_tuning)
+            torch.cuda.tunable.enable(was_on)
+    assert (got - want).abs().max().item() <= 1e-4
 
 
 def test_relation_bias_config4_900_queries():

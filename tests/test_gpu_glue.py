@@ -548,8 +548,9 @@ def test_detections_kernel_is_the_torch_sequence_bit_for_bit(monkeypatch):
     boxes = torch.cat([torch.rand(B, N, 2, generator=g), torch.rand(B, N, 2, generator=g) * 0.5], -1).to(DEV)
     sizes = torch.tensor([[800, 1333], [640, 480], [1216, 2016]], device=DEV)
     got = select_detections(logits, boxes, sizes)
-    monkeypatch.setenv("RDETR_DETECTIONS_KERNEL", "0")
-    want = select_detections(logits, boxes, sizes)
+    from relation_detr_amd import options
+    import dataclasses
+    want = select_detections(logits, boxes, sizes, opts=dataclasses.replace(options.get(), detections_kernel=False))
     assert got.shape == (B, 300, 6) and torch.equal(got, want)
 
 

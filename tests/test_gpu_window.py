@@ -102,6 +102,56 @@ def test_window_matches_oracle_and_direct(ops, shapes, B, spread_px, scatter, po
     assert np.array_equal(auto, direct) or np.array_equal(auto, out)
 
 
+@pytest.mark.parametrize("case", ["gap", "unordered", "short", "level1_larger"])
+def test_auto_never_takes_the_window_kernel_on_levels_that_do_not_tile_the_value(ops, case):
+    """The window kernel enumerates its queries as the pixels of the levels, so it is only correct when the levels tile [0, S)
+    (include/relation_detr_amd.h, RDETR_MSDA_WINDOW precondition).  The reference operator accepts any table whose levels fit
+    (ms_deform_im2col_cuda.cuh:263-267 only indexes with level_start_index): gaps between levels, levels stored out of order,
+    a value tensor longer than the levels, a level larger than level 0.  With Nq == S >= 4096, L == 4, bf16 -- the shape where
+    'auto' would otherwise pick the window kernel -- the result must still be the oracle's, every output row written."""
+    from oracle import c_oracle
+    from relation_detr_amd import _lib
+    shapes = [(64, 96), (32, 48), (16, 24), (8, 12)]
+    areas = [h * w for h, w in shapes]
+    if case == "gap":                                    # 100 unused positions between level 0 and level 1
+        starts = [0, areas[0] + 100, areas[0] + 100 + areas[1], areas[0] + 100 + areas[1] + areas[2]]
+        S = starts[3] + areas[3]
+    elif case == "unordered":                            # levels stored coarsest first
+        starts = [areas[3] + areas[2] + areas[1], areas[3] + areas[2], areas[3], 0]
+        S = sum(areas)
+    elif case == "short":                                # value longer than the levels
+        starts = [0, areas[0], areas[0] + areas[1], areas[0] + areas[1] + areas[2]]
+        S = sum(areas) + 333
+    else:                                                # cumulative and complete, but level 1 outgrows level 0
+        shapes = [(32, 48), (64, 96), (16, 24), (8, 12)]
+        areas = [h * w for h, w in shapes]
+        starts = [0, areas[0], areas[0] + areas[1], areas[0] + areas[1] + areas[2]]
+        S = sum(areas)
+    shp = torch.tensor(shapes, dtype=torch.int64)
+    start = torch.tensor(starts, dtype=torch.int64)
+    assert not ops.levels_window_ok(shp.to(DEV), start.to(DEV), S)
+    g = torch.Generator().manual_seed(len(case))
+    B, L = 2, 4
+    value = torch.randn(B, S, 8, 32, generator=g).to(torch.bfloat16)
+    loc = torch.rand(B, S, 8, L, 4, 2, generator=g) * 1.2 - 0.1
+    attn = torch.softmax(torch.randn(B, S, 8, L * 4, generator=g), -1).view(B, S, 8, L, 4)
+    ref = c_oracle.msda_forward(value.float().numpy(), shp.numpy(), start.numpy(), loc.numpy(), attn.numpy())
+    rest = (shp.to(DEV), start.to(DEV), loc.to(DEV), attn.to(DEV))
+    for layout, v in (("bshd", value.to(DEV)), ("bhsd", _head_major(value.to(DEV)))):
+        out = ops.ms_deform_attn_forward(v, *rest, value_layout=layout).float().cpu().numpy()        # algo = "auto"
+        _check(out, ref)
+        with pytest.raises(_lib.RdetrError):
+            ops.ms_deform_attn_forward(v, *rest, value_layout=layout, algo="window")
+    # the plain C entry point (the `_C` contract, no algo argument) is the direct kernel: safe for any table
+    lib = _lib.load()
+    v = value.to(DEV)
+    out = torch.full((B, S, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    st = lib.rdetr_msda_forward_bf16(v.data_ptr(), rest[0].data_ptr(), rest[1].data_ptr(), rest[2].data_ptr(), rest[3].data_ptr(),
+                                     B, S, 8, 32, L, S, 4, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    _check(out.float().cpu().numpy(), ref)
+
+
 def test_value_to_head_major(ops):
     g = torch.Generator().manual_seed(3)
     B, S = 3, 1000 + 37
@@ -239,7 +289,8 @@ def test_module_head_major_route_matches_operator_layout_route_and_oracle(shapes
                 spatial_shapes=shp.to(DEV), level_start_index=start.to(DEV), key_padding_mask=mask.to(DEV))
     with torch.no_grad():
         hm = md(**args).float().cpu()
-        monkeypatch.setenv("RDETR_VALUE_HEAD_MAJOR", "0")
+        from relation_detr_amd import options
+        options.apply(md, value_head_major=False)
         plain = md(**args).float().cpu()
         params = {k: v.to(torch.bfloat16).float() for k, v in m.state_dict().items()}          # the bf16-rounded weights, fp32 math
         want = torch_ref.msda_module_forward(params, (src + pos).to(torch.bfloat16).float(), ref, src.to(torch.bfloat16).float(),

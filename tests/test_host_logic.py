@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().rdetr_abi_version() == 2
+    assert _lib.load().rdetr_abi_version() == 3
     assert _lib.load().rdetr_status_string(-2).decode().startswith("shape not supported")
     assert _lib.load().rdetr_msda_fast_path(8, 32, 4, 4) == 1
     assert _lib.load().rdetr_msda_fast_path(8, 32, 5, 4) == 1
@@ -167,3 +167,45 @@ def test_packed_weight_cache_is_tied_to_tensor_objects():
         t = torch.full((2, 2), float(i))
         assert torch.equal(cache.get((t,), build_for(t)), t * 2)
     assert len(cache) <= 5
+
+
+def test_levels_window_ok_host_helper():
+    """rdetr_msda_levels_window_ok: the precondition of RDETR_MSDA_WINDOW / _AUTO_PACKED, pure host arithmetic."""
+    import ctypes
+    from relation_detr_amd import _lib
+    lib = _lib.load()
+
+    def ok(shapes, starts, S):
+        hs = (ctypes.c_int64 * (2 * len(shapes)))(*[v for hw in shapes for v in hw])
+        st = (ctypes.c_int64 * len(starts))(*starts)
+        return bool(lib.rdetr_msda_levels_window_ok(hs, st, len(shapes), S))
+
+    r50 = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    starts = [0, 16800, 21000, 22050]
+    assert ok(r50, starts, 22323)
+    assert not ok(r50, starts, 22324)                               # value longer than the levels
+    assert not ok(r50, [0, 16900, 21100, 22150], 22423)             # gap after level 0
+    assert not ok(r50[::-1], [0, 273, 1323, 5523], 22323)           # cumulative but growing: level 1 outgrows level 0
+    assert not ok(r50, [22050 - 16800, 0, 1, 2], 22323)             # not cumulative
+    assert not ok([(0, 5)], [0], 0)
+
+
+def test_options_object():
+    """One immutable options object: read from the environment once, copied by modules at construction, replaceable per
+    module tree -- nothing on a forward path reads the environment (VERDICT r02 hygiene item 13)."""
+    import dataclasses
+    import inspect
+    from relation_detr_amd import ms_deform_attn, options, transformer
+    o = options.Options.from_env({"RDETR_FFN_FUSED": "0", "RDETR_LINEAR_K256": "1", "RDETR_MASK_IN_KERNEL": "never", "OTHER": "x"})
+    assert (o.ffn_fused, o.linear_k256, o.mask_in_kernel, o.rel_fused) == (False, True, "never", True)
+    with pytest.raises(ValueError):
+        options.Options.from_env({"RDETR_TOPK": "yes"})
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        o.topk = False
+    with options.override(rel_fused=False):
+        net = transformer.build_relation_transformer(num_classes=3, d_ffn=16, enc_layers=1, dec_layers=1, num_queries=4)
+    assert net.decoder.options.rel_fused is False and options.get().rel_fused is True
+    options.apply(net, rel_fused=True, box_head=False)
+    assert all(m.options.rel_fused and not m.options.box_head for m in net.modules() if hasattr(m, "options"))
+    for mod in (transformer, ms_deform_attn):
+        assert "os.environ" not in inspect.getsource(mod)

@@ -37,7 +37,8 @@ import time
 # The dense layers of the stack are library GEMMs (hipBLASLt / rocBLAS).  PyTorch's TunableOp can pick the fastest library
 # kernel per GEMM shape during the warm-up steps (about 20 shapes, ~5 s; +1.5-3.6 % images/s) -- OPT-IN
 # (RDETR_BENCH_TUNABLEOP=1, set before torch is imported): `value` is measured with the library's own heuristics, the tuned
-# rate is a side value from a child process (`value_gemm_tuned`).  Round 2's headline depended on tuning, and tuning is what
+# rate is an optional side value from a child process (`value_gemm_tuned`, RDETR_BENCH_TUNED_SIDE=1; measured 923 tuned vs 975
+# untuned images/s on the same box in round 3 -- tuning no longer pays).  Round 2's headline depended on tuning, and tuning is what
 # faulted the GPU twice in round 2 (TunableOp undersizes its scratch copy of a strided-batched operand whose leading
 # dimension exceeds its row length, DESIGN.md 5 -- the operands this package hands the library are dense now, but the
 # headline should not depend on a tuner).
@@ -85,13 +86,24 @@ def build_pyramid(B, dev, seed, dtype=torch.float32, shapes=R50_SHAPES):
     return feats, masks, pos
 
 
-def build_network(Nq, seed=0, num_levels=4, class_scale=1.0, **classes):
+def build_network(Nq, seed=0, num_levels=4, class_scale=3.0, exchangeable_queries=True, box_head_std=0.01, **classes):
     """Random-init RelationTransformer of the R50 / FocalNet-L config (they differ in the level count only,
     configs/relation_detr/relation_detr_focalnet_large_lrf_fl4_1200_2000.py:20-29); fresh MSDA modules have zero offset /
     attention weights (ms_deform_attn.py:268,279-280), so those get a trained-like spread to make the gather data dependent.
-    ``class_scale``: factor on the weights of every class head (encoder, decoder layers, hybrid).  At 1.0 (the init the
-    reference uses, and what `value` is measured with) all class logits sit within a few 1e-2 of the prior bias, below bf16
-    resolution; tests that compare DETECTIONS between two arithmetic routes use a larger spread (tests/test_gpu_fullsize.py)."""
+    Three more departures from the reference's init, none of which changes a shape, a launch or a FLOP -- they make the
+    DETECTIONS of two arithmetic routes (bf16 vs fp32, replay vs eager) comparable, measured by tools/exp_separation.py
+    (profiles/r03/detection_separation.txt):
+    ``class_scale``: factor on the weights of every class head (encoder, decoder layers, hybrid).  At 1.0 the final scores
+    span 0.04-0.08; at 3.0 they span 0.4-0.7 (logit spread ~ +-1.5 around the prior, no sigmoid saturation: at 8 the top
+    scores are all 1.0 in fp32).
+    ``box_head_std``: the last layer of every box head is ZERO in the reference's init (relation_transformer.py:304-305), so
+    the refined boxes would equal the proposals through all six layers and the box path would never be exercised; N(0, std)
+    weights give refinements of ~0.1 in logit space per layer.
+    ``exchangeable_queries``: every row of ``tgt_embed`` (the content query of slot r, relation_transformer.py:117) gets the
+    values of row 0.  The two-stage selection hands slot r the r-th best proposal; with N(0,1) rows every slot is a different
+    random function of its proposal, so two routes that agree on the proposal SET but order near-equal scores differently
+    (bf16 noise is ~20 rank spacings) produce unrelated detections.  With equal rows the decoder is permutation-equivariant
+    in its proposals and a detection match measures arithmetic, not slot assignment."""
     from relation_detr_amd.transformer import build_relation_transformer
     torch.manual_seed(seed)
     net = build_relation_transformer(num_classes=91, d_ffn=2048, enc_layers=6, dec_layers=6, num_queries=Nq,
@@ -102,6 +114,11 @@ def build_network(Nq, seed=0, num_levels=4, class_scale=1.0, **classes):
             if hasattr(mod, "sampling_offsets"):
                 mod.sampling_offsets.weight.copy_(torch.randn(mod.sampling_offsets.weight.shape, generator=g) * 0.02)
                 mod.attention_weights.weight.copy_(torch.randn(mod.attention_weights.weight.shape, generator=g) * 0.05)
+        if exchangeable_queries:
+            net.tgt_embed.weight.copy_(net.tgt_embed.weight[:1].expand_as(net.tgt_embed.weight).clone())
+        if box_head_std:
+            for head in (net.encoder_bbox_head, net.hybrid_bbox_head, *net.decoder.bbox_head):
+                head.layers[-1].weight.copy_(torch.randn(head.layers[-1].weight.shape, generator=g) * box_head_std)
         if class_scale != 1.0:
             for head in (net.encoder_class_head, net.hybrid_class_head, *net.decoder.class_head):
                 head.weight.mul_(class_scale)
@@ -391,13 +408,6 @@ def main():
     if args.batch is None:
         args.batch = cfg["batch"]
     tuned = os.environ.get("PYTORCH_TUNABLEOP_ENABLED", "0") == "1"
-    if args.dtype == "fp32" and not args.no_graph and not tuned:
-        # Capturing the fp32 stack with the library's default GEMM selection stopped making progress on this image in round 2
-        # (full size; cause in DESIGN.md 5).  No configuration of this script may hang a GPU: fp32 without tuned GEMMs is
-        # enqueued from Python.  RDETR_BENCH_FP32_GRAPH=1 forces the capture (tools/exp_fp32_capture.py runs that under a timeout).
-        if os.environ.get("RDETR_BENCH_FP32_GRAPH") != "1":
-            print("[bench] --dtype fp32 without GEMM tuning: running eagerly (--no-graph)", file=sys.stderr)
-            args.no_graph = True
 
     # ---- one process per GPU -------------------------------------------------------------------------------------------
     # Launched by torch.distributed.run (RANK / WORLD_SIZE in the environment): this process is one rank.  Launched bare
@@ -439,9 +449,15 @@ def main():
     # The images of a batch are independent, so the batch runs as `nstreams` image groups on parallel HIP streams, forked and
     # joined inside the captured graph (relation_detr_amd/graph.py::ImageGroups): the gather-bound kernels of one group
     # overlap the MFMA-bound GEMMs of the other.  Same kernels, same results per image.  RDETR_BENCH_STREAMS=1: one stream.
-    nstreams = int(os.environ.get("RDETR_BENCH_STREAMS", "2" if B % 2 == 0 else "1"))
+    # fp32: ONE group.  Two fp32 image groups side by side stop making progress on this image -- eagerly and under capture alike,
+    # every piece of the stack and the whole one-group stack capture and replay fine (tools/exp_fp32_capture.py, DESIGN.md 5:
+    # what co-runs are the library's fp32 GEMM kernels of the two groups).  No configuration of this script may hang a GPU, so
+    # an explicit RDETR_BENCH_STREAMS > 1 is refused for fp32.
+    nstreams = int(os.environ.get("RDETR_BENCH_STREAMS", "2" if B % 2 == 0 and args.dtype == "bf16" else "1"))
     if nstreams < 1 or B % nstreams:
         raise SystemExit("RDETR_BENCH_STREAMS must divide --batch")
+    if args.dtype == "fp32" and nstreams > 1 and os.environ.get("RDETR_BENCH_FP32_GROUPS_UNSAFE") != "1":
+        raise SystemExit("[bench] fp32 runs as one image group (two fp32 groups side by side hang on this image, DESIGN.md 5)")
 
     def make_runner(queries, net_dtype, inputs):
         """(callable, launch mode) of the whole stack + top-300 detections for one network configuration."""
@@ -532,7 +548,7 @@ def main():
             if cp.returncode == 0 and line:
                 fp32_ips = json.loads(line[-1])["value"]
                 dets32 = torch.load(dump, weights_only=True).to(dev)
-                drift = detection_drift(dets_main.float(), dets32, iou_thr=0.5)
+                drift = detection_drift(dets_main.float(), dets32, iou_thr=0.9)
             else:
                 print(f"[bench] fp32 side run failed (exit {cp.returncode}): {cp.stderr[-300:]}", file=sys.stderr)
         except (subprocess.TimeoutExpired, RuntimeError, OSError) as e:
@@ -541,7 +557,7 @@ def main():
             if os.path.exists(dump):
                 os.remove(dump)
 
-    if extras and args.dtype == "bf16" and not tuned and os.environ.get("RDETR_BENCH_TUNED_SIDE", "1") != "0":
+    if extras and args.dtype == "bf16" and not tuned and os.environ.get("RDETR_BENCH_TUNED_SIDE", "0") == "1":
         # The same bf16 run with PyTorch's TunableOp choosing the library GEMM kernels, in a child process (a tuner fault
         # cannot take the headline down): side value only.
         import subprocess
@@ -578,6 +594,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "queries": Nq,
                        "queries_note": "value: 900 two-stage queries (what the reference config runs), 300 detections kept; "
                                        "value_300_queries: 300 two-stage queries (BASELINE.json's wording)",
+                       "weights": "random init (seeded); MSDA offset / attention projections N(0, .02) / N(0, .05), class heads x3, "
+                                  "last box-head layers N(0, .01), tgt_embed rows equal -- see build_network",
                        "levels": L, "fp32_images_per_s": fp32_ips, "bf16_vs_fp32_detections": drift,
                        "launch": launch, "streams": nstreams,
                        "gemm_tuning": tuned,

@@ -86,30 +86,31 @@ def test_fp32_stack_matches_cpu_oracle_full_size(bench, config, queries):
     np.testing.assert_allclose(g_cls.float().cpu().numpy(), c_cls.numpy(), rtol=0, atol=5e-4)
     np.testing.assert_allclose(g_box.float().cpu().numpy(), c_box.numpy(), rtol=0, atol=5e-4)
     # and the harness's own decoder outputs are the ones just checked (same proposals in, same kernels)
-    np.testing.assert_allclose(got[0].float().cpu().numpy(), g_cls.float().cpu().numpy(), rtol=0, atol=1e-5)
-
-
-CLASS_SCALE = 32.0          # class-head weight scale of the detection-level comparisons (bench.build_network): logits spread
-                            # over ~+-1.5 around the prior instead of ~+-0.05, i.e. far above bf16 resolution (ulp 0.03 at 4.6)
+    # (the full forward takes its valid ratios / reference points from rdetr_pyramid_points, the re-run from the torch
+    # statements: equal up to the last bit, which six layers turn into <= 1e-3 on logits of +-7 at 204k tokens)
+    np.testing.assert_allclose(got[0].float().cpu().numpy(), g_cls.float().cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
 def test_bf16_two_group_replay_vs_fp32_full_size(bench):
-    """bench.py's default launch against the fp32 harness, on a network whose class scores are SEPARATED (CLASS_SCALE): with
-    the reference's init every class logit sits within a few 1e-2 of the prior bias, below bf16 resolution, and a detection
-    match between the two arithmetic routes says nothing.
-      * encoder memory bf16 vs fp32: relative L2 < 2^-5; replay vs eager: bit-identical detections (own total-order top-k,
-        csrc/topk.hip -- nothing on the path is order-dependent any more);
-      * detections bf16 vs fp32 at IoU 0.9, same label: the bound below.  What keeps it from 1.0 is structural, not noise in a
-        kernel: the two-stage cut ranks 22,323 continuous scores and hands query slot r the r-th best proposal; bf16 noise of
-        ~1 % of the score spread is ~20 rank spacings at the cut, so a few per cent of the proposals change slots or drop out.
-        The decoder itself is bounded on IDENTICAL proposals by test_bf16_decoder_on_identical_proposals_full_size."""
+    """bench.py's default launch against the fp32 harness, on bench.py's network (build_network: class heads x3 so the scores
+    are spread far above bf16 resolution, box heads that move the boxes, exchangeable content queries).
+      * encoder memory bf16 vs fp32: relative L2 < 2^-5;
+      * replay vs eager: every detection reproduced (>= 0.99 at IoU 0.9; measured bit-identical: both selections are
+        rdetr_topk's total order, nothing on the path is order-dependent any more);
+      * detections bf16 vs fp32 at IoU 0.9, same label: >= 0.95 (measured 0.97, tools/exp_separation.py).
+    Why `exchangeable_queries`: the two-stage cut ranks 22,323 continuous scores and hands query slot r the r-th best proposal.
+    bf16 noise of ~1 % of the score spread is ~20 rank spacings, so the two routes agree on 99 % of the proposal SET but on 5 %
+    of the SLOTS (measured), and with N(0,1) tgt_embed rows every slot is a different random function of its proposal: 0.44-0.48
+    matched whatever the class scale -- a property of a random-init decoder, not of a kernel.  With equal rows the decoder is
+    permutation-equivariant and the match measures arithmetic.  The decoder is bounded on IDENTICAL proposals by
+    test_bf16_decoder_on_identical_proposals_full_size."""
     from relation_detr_amd.graph import GraphedCall, ImageGroups
     from relation_detr_amd.transformer import select_detections
     B, L = 4, 4
     feats, masks, pos = bench.build_pyramid(B, DEV, seed=1000, dtype=torch.float32)
     sizes = torch.tensor([[800, 1333]] * B, device=DEV)
-    net32 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV)
-    net16 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV).to(torch.bfloat16)
+    net32 = bench.build_network(900, 0).to(DEV)
+    net16 = bench.build_network(900, 0).to(DEV).to(torch.bfloat16)
     mem = {"fp32": [], "bf16": []}                       # per image group, in launch order
     net32.encoder.register_forward_hook(lambda m, i, o: mem["fp32"].append(o.detach().float().clone()))
     net16.encoder.register_forward_hook(lambda m, i, o: mem["bf16"].append(o.detach().float().clone()))
@@ -151,7 +152,7 @@ def test_bf16_two_group_replay_vs_fp32_full_size(bench):
     assert d5["matched_frac"] >= d9["matched_frac"]
 
 
-BF16_MATCH_IOU90 = 0.5       # calibrated on the GPU (tools/exp_separation.py): see the docstring above
+BF16_MATCH_IOU90 = 0.95
 
 
 def test_bf16_decoder_on_identical_proposals_full_size(bench):
@@ -164,8 +165,8 @@ def test_bf16_decoder_on_identical_proposals_full_size(bench):
     for l in range(L):
         w = masks[l].shape[2]
         masks[l][1, :, w * 150 // 168:] = True
-    net32 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV)
-    net16 = bench.build_network(900, 0, class_scale=CLASS_SCALE).to(DEV).to(torch.bfloat16)
+    net32 = bench.build_network(900, 0).to(DEV)
+    net16 = bench.build_network(900, 0).to(DEV).to(torch.bfloat16)
     seen = {}
     net32.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("memory", o.detach().clone()))
     with torch.no_grad():
@@ -177,16 +178,17 @@ def test_bf16_decoder_on_identical_proposals_full_size(bench):
                   valid_ratios=vr)
         c32, b32 = net32.decoder(query=net32.tgt_embed.weight.expand(B, -1, -1), value=memory, **kw)
         c16, b16 = net16.decoder(query=net16.tgt_embed.weight.expand(B, -1, -1), value=memory.to(torch.bfloat16), **kw)
-    np.testing.assert_allclose(got[0].float().cpu().numpy(), c32.cpu().numpy(), rtol=0, atol=1e-5)   # same proposals in, same kernels
+    np.testing.assert_allclose(got[0].float().cpu().numpy(), c32.cpu().numpy(), rtol=1e-4, atol=5e-4)   # same proposals in, same kernels
     c32, b32, c16, b16 = c32.float(), b32.float(), c16.float(), b16.float()
     assert torch.isfinite(c16).all() and torch.isfinite(b16).all()
-    spread = (c32 - c32.mean()).abs().max().item()               # logits: O(1-5) around the prior with CLASS_SCALE
+    spread = (c32 - c32.mean()).abs().max().item()               # logits: O(1-5) around the prior (class heads x3)
     dbox, dcls = (b16 - b32).abs(), (c16 - c32).abs()
     print(f"bf16 decoder vs fp32 on identical proposals: boxes max {dbox.max().item():.4f} mean {dbox.mean().item():.5f}; "
           f"logits max {dcls.max().item():.4f} mean {dcls.mean().item():.5f} (spread {spread:.2f}); per layer box max "
           f"{[round(v, 4) for v in dbox.amax((1, 2, 3)).tolist()]} logit max {[round(v, 4) for v in dcls.amax((1, 2, 3)).tolist()]}")
-    assert dbox.max().item() <= 2e-2 and dbox.mean().item() <= 2e-3
-    assert dcls.max().item() <= 2.0 ** -3 * spread and dcls.mean().item() <= 2.0 ** -6 * spread
+    # measured: boxes max 1.7e-3 / mean 8e-5, logits max 0.146 / mean 0.011 at a spread of 6.9 (profiles/r03/gpu_tests_tail.txt)
+    assert dbox.max().item() <= 5e-3 and dbox.mean().item() <= 3e-4
+    assert dcls.max().item() <= 2.0 ** -5 * spread and dcls.mean().item() <= 2.0 ** -8 * spread
 
 
 def test_bf16_focalnet_5_level_stack_full_size(bench):

@@ -70,24 +70,41 @@ def test_harness_with_hip_modules_matches_reference(golden, fixture, dtype):
 
 
 def _bf16_harness_vs_fixture(g, net, feats, masks, pos):
-    """The bf16 inference route (fused-producer MSDA on head-major value, generated-bias attention, the glue kernels) on the
-    reference's fixture.  The fixture's two-stage scores are separated by far more than bf16 resolution only for some
-    proposals, so the discrete choice may differ: the ENCODER outputs are compared as sets (every reference proposal's box
-    is found among ours), and the decoder is held to a bf16-sized bound on the queries whose proposals coincide."""
+    """The bf16 inference route (fused-producer MSDA on head-major value where it applies, generated-bias attention, fused box
+    head, the glue kernels) on the reference's fixture network, 4 and 5 levels.
+    (i)  Whole forward in bf16: finite, right shapes, and the two-stage proposals agree with the reference's as a SET (bf16
+         reorders near-equal scores, so slots differ -- tests/test_gpu_fullsize.py explains why that is not comparable).
+    (ii) The continuous bound: bf16 decoder vs fp32 decoder of the same network on IDENTICAL inputs -- the fp32 run's encoder
+         memory and proposals, that fp32 run being the one the fp32 case of this test pins to the reference's fixture."""
+    import copy
     dev = "cuda:0"
-    net = net.to(dev).to(torch.bfloat16)
+    net32 = net.to(dev)
+    net16 = copy.deepcopy(net32).to(torch.bfloat16)
+    f32, m32, p32 = [f.to(dev) for f in feats], [m.to(dev) for m in masks], [p.to(dev) for p in pos]
+    seen = {}
+    net32.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("memory", o.detach().clone()))
     with torch.no_grad():
-        outs = net([f.to(dev).to(torch.bfloat16) for f in feats], [m.to(dev) for m in masks],
-                   [p.to(dev).to(torch.bfloat16) for p in pos])
+        outs = net16([f.to(torch.bfloat16) for f in f32], m32, [p.to(torch.bfloat16) for p in p32])
+        ref_outs = net32(f32, m32, p32)
     oc, ob, ec, eb = [o.float().cpu().numpy() for o in outs[:4]]
-    assert np.isfinite(oc).all() and np.isfinite(ob).all()
+    assert np.isfinite(oc).all() and np.isfinite(ob).all() and np.isfinite(ec).all() and np.isfinite(eb).all()
     assert oc.shape == g["out_classes"].shape and ob.shape == g["out_coords"].shape
-    # encoder proposals: same boxes (sigmoid space) within bf16 noise wherever the same token was picked, in the same slot
-    same = np.abs(eb - g["enc_coords"]).max(-1) < 2e-2                     # [B, N]
-    assert same.mean() >= 0.8, same.mean()
-    np.testing.assert_allclose(ec[same], g["enc_classes"][same], rtol=0, atol=6e-2)
-    # decoder: images whose proposal sets coincide completely are comparable query by query (self-attention mixes queries)
-    full = same.all(1)
-    assert full.any(), "no image kept its full proposal set in bf16 -- fixture no longer discriminates"
-    np.testing.assert_allclose(ob[:, full], g["out_coords"][:, full], rtol=0, atol=3e-2)
-    np.testing.assert_allclose(oc[:, full], g["out_classes"][:, full], rtol=0, atol=0.15)
+    d = np.abs(eb[:, :, None, :] - g["enc_coords"][:, None, :, :]).max(-1)            # [B, ours, reference]
+    common = (d.min(1) < 2e-2).mean()
+    print("bf16 two-stage proposals also picked by the reference:", common)
+    assert common >= 0.7, common
+    B = f32[0].shape[0]
+    with torch.no_grad():
+        geo, vr = net32.level_misc(m32)
+        kw = dict(key_padding_mask=net32.flatten_levels(m32), reference_points=ref_outs[3].float().detach(),
+                  spatial_shapes=geo["shapes"], level_start_index=geo["start"], valid_ratios=vr)
+        c32, b32 = net32.decoder(query=net32.tgt_embed.weight.expand(B, -1, -1), value=seen["memory"], **kw)
+        c16, b16 = net16.decoder(query=net16.tgt_embed.weight.expand(B, -1, -1), value=seen["memory"].to(torch.bfloat16), **kw)
+    np.testing.assert_allclose(c32.cpu().numpy(), g["out_classes"], rtol=0, atol=5e-4)      # the fp32 side IS the fixture's decoder
+    np.testing.assert_allclose(b32.cpu().numpy(), g["out_coords"], rtol=0, atol=5e-4)
+    dbox, dcls = (b16.float() - b32).abs(), (c16.float() - c32).abs()
+    scale = c32.abs().max().item()
+    print(f"bf16 decoder vs fp32 on identical proposals ({geo['shapes'].shape[0]} levels): boxes max {dbox.max().item():.4f} mean "
+          f"{dbox.mean().item():.5f}; logits max {dcls.max().item():.4f} mean {dcls.mean().item():.5f} (scale {scale:.2f})")
+    assert dbox.max().item() <= 5e-3 and dbox.mean().item() <= 5e-4
+    assert dcls.max().item() <= 2.0 ** -4 * scale and dcls.mean().item() <= 2.0 ** -7 * scale

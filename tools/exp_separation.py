@@ -29,15 +29,17 @@ def make(net, L):
 
 
 def main():
-    scales = [float(v) for v in sys.argv[1:]] or [1.0, 8.0, 32.0, 128.0]
+    scales = [float(v) for v in sys.argv[1:] if not v.startswith("--")] or [1.0, 8.0, 32.0, 128.0]
+    exch = "--exchangeable" in sys.argv
+    box_std = 0.0 if "--static-boxes" in sys.argv else 0.01
     B, L = 4, 4
     feats, masks, pos = bench.build_pyramid(B, DEV, seed=1000, dtype=torch.float32)
     sizes = torch.tensor([[800, 1333]] * B, device=DEV)
     in32 = [*feats, *masks, *pos, sizes]
     in16 = [t.to(torch.bfloat16) if t.is_floating_point() else t for t in in32]
     for sc in scales:
-        net32 = bench.build_network(900, 0, class_scale=sc).to(DEV)
-        net16 = bench.build_network(900, 0, class_scale=sc).to(DEV).to(torch.bfloat16)
+        net32 = bench.build_network(900, 0, class_scale=sc, exchangeable_queries=exch, box_head_std=box_std).to(DEV)
+        net16 = bench.build_network(900, 0, class_scale=sc, exchangeable_queries=exch, box_head_std=box_std).to(DEV).to(torch.bfloat16)
         det32, prop32 = make(net32, L)(*in32)
         det32, prop32 = det32.clone(), prop32.clone()
         det16, prop16 = ImageGroups(make(net16, L), 2, device=DEV)(*in16)
@@ -50,7 +52,7 @@ def main():
         any_slot = (d.min(1)[0] < 2e-2).float().mean().item()
         same_slot = ((prop16 - prop32).abs().max(-1)[0] < 2e-2).float().mean().item()
         logits = net32.encoder_class_head.weight.std().item()
-        out = {"class_scale": sc, "class_head_weight_std": round(logits, 4), "proposals_common": round(any_slot, 4),
+        out = {"class_scale": sc, "exchangeable_queries": exch, "box_head_std": box_std, "class_head_weight_std": round(logits, 4), "proposals_common": round(any_slot, 4),
                "proposals_same_slot": round(same_slot, 4)}
         for thr in (0.5, 0.9):
             m = bench.detection_drift(det16, det32, iou_thr=thr)
@@ -59,6 +61,8 @@ def main():
         out["replay_bit_identical"] = bool(torch.equal(rdet16, det16))
         s32 = det32[..., 4]
         out["fp32_score_range"] = [round(s32.min().item(), 4), round(s32.max().item(), 4)]
+        out["fp32_distinct_scores"] = int(torch.unique(s32).numel())
+        out["fp32_distinct_boxes"] = int(torch.unique(det32[..., :4].reshape(-1, 4), dim=0).shape[0])
         print(out, flush=True)
         del net32, net16, run
 

@@ -148,10 +148,15 @@ def encoder_kernel_inputs(B, dev, dtype, level_shapes=R50_SHAPES):
     return value, shapes.to(dev), start.to(dev), loc, attn, S, L
 
 
-def time_encoder_kernel(B, dev, dtype, reps=20, layout=None, level_shapes=R50_SHAPES):
+def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SHAPES, busy=None):
     """Average duration of the dominant kernel from device events recorded on the stream it is launched on.
     layout None = the one the stack runs the kernel in: head-major [B,H,S,D] for bf16 (written by the value projection's
-    epilogue, relation_detr_amd/ms_deform_attn.py), the reference operator's [B,S,H,D] for fp32."""
+    epilogue, relation_detr_amd/ms_deform_attn.py), the reference operator's [B,S,H,D] for fp32.
+    ``busy``: a callable that enqueues ~50 ms of the stack's own work.  It runs right before the timed launches, with no host
+    synchronisation in between, so that the kernel is timed at the clocks the stack runs it at: after an idle gap (the inputs
+    are built on the host) the first ~200 launches run at ramping clocks -- 135 -> 107 us over 25 ms, 119 us after a 50-ms
+    pause (tools/exp_kernel_timing.py, profiles/r03/kernel_timing_vs_clock_ramp.txt); round 2's 3 warm-up + 20 timed launches
+    measured the ramp."""
     import relation_detr_amd as rd
     value, shapes, start, loc, attn, S, L = encoder_kernel_inputs(B, dev, dtype, level_shapes)
     if layout is None:
@@ -162,6 +167,8 @@ def time_encoder_kernel(B, dev, dtype, reps=20, layout=None, level_shapes=R50_SH
     for _ in range(3):
         rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64, **kw)
     torch.cuda.synchronize()
+    if busy is not None:
+        busy()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -509,9 +516,13 @@ def main():
         el = max(per_rank)                                  # MAX over ranks
 
     note(f"timed loop done: {world * B * args.steps / el:.1f} images/s; dominant kernel")
-    t_kernel, S, L = time_encoder_kernel(B, dev, dtype, level_shapes=cfg["shapes"])
-    t_kernel_bshd = time_encoder_kernel(B, dev, dtype, layout="bshd", level_shapes=cfg["shapes"])[0] if args.dtype == "bf16" else None
-    t_kernel_fp32 = time_encoder_kernel(B, dev, torch.float32, level_shapes=cfg["shapes"])[0] if args.dtype == "bf16" else None
+    def busy():                                             # ~50 ms of the stack itself, enqueued without a host sync
+        for _ in range(max(4, int(0.05 * args.steps / max(el, 1e-6)))):
+            run(*flat_inputs)
+
+    t_kernel, S, L = time_encoder_kernel(B, dev, dtype, level_shapes=cfg["shapes"], busy=busy)
+    t_kernel_bshd = time_encoder_kernel(B, dev, dtype, layout="bshd", level_shapes=cfg["shapes"], busy=busy)[0] if args.dtype == "bf16" else None
+    t_kernel_fp32 = time_encoder_kernel(B, dev, torch.float32, level_shapes=cfg["shapes"], busy=busy)[0] if args.dtype == "bf16" else None
     note("side measurements")
     alg = msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2 if args.dtype == "bf16" else 4)
 

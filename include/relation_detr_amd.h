@@ -195,6 +195,22 @@ int rdetr_relation_bias_ws_f32(const float *src, const float *tgt, const float *
                                int B, int N1, int N2, int Hh, int F, float scale, float temperature, float eps,
                                float *workspace, float *out, void *stream);
 
+/* Backward of the relation bias with respect to the 1x1 projection -- what autograd computes for
+ * PositionRelationEmbedding.pos_proj in training (models/bricks/relation_transformer.py:527-532; the boxes carry no gradient,
+ * :527-529):
+ *     grad_weight[h][ch] = sum_{b,i,j} g[b,h,i,j] * feat[b,i,j,ch],   grad_bias[h] = sum g,   g = grad_out where active else 0
+ * with the 64 sine features REGENERATED from the boxes by the forward's arithmetic (the reference keeps [N1, N2, 64] per image
+ * for its backward GEMM: 207 MB at N = 900).
+ *   src [B,N1,4], tgt [B,N2,4] fp32 cxcywh (tgt 16-byte aligned); grad_out [B,Hh,N1,N2] fp32; active u8 [B,Hh,N1,N2] = (forward
+ *   output > 0), the ReLU's derivative; workspace: rdetr_relation_bias_backward_workspace_bytes(B, N1, N2) bytes;
+ *   grad_weight [Hh, 4F] fp32, grad_bias [Hh] fp32 or NULL -- both OVERWRITTEN (no zero-initialisation needed).
+ * DETERMINISTIC: per-block partial sums go to the workspace and a second kernel adds them in a fixed order (no float atomics).
+ * Hh = 8, F = 16 only (RDETR_ERR_UNSUPPORTED otherwise). */
+long long rdetr_relation_bias_backward_workspace_bytes(int B, int N1, int N2);
+int rdetr_relation_bias_backward_f32(const float *src, const float *tgt, const float *grad_out, const uint8_t *active, int B, int N1,
+                                     int N2, int Hh, int F, float scale, float temperature, float eps, float *workspace,
+                                     float *grad_weight, float *grad_bias, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bias-add + row softmax of decoder self-attention scores, in place.
  * Replaces the softmax(QK^T/sqrt(d) + attn_mask) step of nn.MultiheadAttention as called at
@@ -329,6 +345,20 @@ int rdetr_box_head_k256_bf16(const uint16_t *xa, long long lda, const uint16_t *
                              const uint16_t *b1, const uint16_t *pw2, const uint16_t *b2, const uint16_t *w3, const uint16_t *b3,
                              const float *reference, int reference_is_logit, float eps, long long M, float *out_a, float *out_b,
                              void *stream);
+
+/* The decoder layer's query position in one launch (models/bricks/relation_transformer.py:294-296, 343-347, 452-455):
+ *     out_pos = ref_point_head(emb)                      MLP(512, 256, 256, 2) on the sine embedding of the reference boxes
+ *     out_pos = out_pos * query_scale(query)             MLP(256, 256, 256, 2), layers >= 1 -- when pv1 / c1 / pv2 / c2 are given
+ *     out_qpp = query + out_pos                          the q = k input of the layer's self-attention
+ * emb [M, 512], query [M, 256] bf16 (row strides lde / ldq elements, multiples of 8, 16-byte aligned bases); pw1a / pw1b = the
+ * K halves [:, :256] / [:, 256:] of ref_point_head.layers[0].weight [256, 512], pw2 = ref_point_head.layers[1].weight, pv1 / pv2 =
+ * query_scale's two [256, 256] weights -- each packed by rdetr_linear_pack_k256_bf16; b1, b2, c1, c2 bf16 [256];
+ * out_pos, out_qpp [M, 256] bf16 contiguous.  Every intermediate is rounded to bf16 where the unfused sequence (four GEMMs, a
+ * product, a sum) stores it. */
+int rdetr_query_pos_k256_bf16(const uint16_t *emb, long long lde, const uint16_t *query, long long ldq, const uint16_t *pw1a,
+                              const uint16_t *pw1b, const uint16_t *b1, const uint16_t *pw2, const uint16_t *b2, const uint16_t *pv1,
+                              const uint16_t *c1, const uint16_t *pv2, const uint16_t *c2, long long M, uint16_t *out_pos,
+                              uint16_t *out_qpp, void *stream);
 
 /* PostProcess after its top-k (models/bricks/post_process.py:30-44) in one launch: for rank r of image b
  *   out[b][r] = (x1, y1, x2, y2, score, label) with box = boxes[b][index / C] (cxcywh in [0, 1]) converted to xyxy and scaled by the

@@ -32,6 +32,8 @@ SIGNATURES = {
     "rdetr_msda_backward_f32": [_vp] * 6 + [_c_int] * 7 + [_vp] * 4,
     "rdetr_relation_bias_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp],
     "rdetr_relation_bias_ws_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp, _vp],
+    "rdetr_relation_bias_backward_workspace_bytes": [_c_int] * 3,
+    "rdetr_relation_bias_backward_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp] * 4,
     "rdetr_bias_softmax_f32": [_vp] * 3 + [_c_int] * 3 + [_vp],
     "rdetr_relation_attention_bf16": [_vp] * 3 + [_c_int] * 3 + [_vp, _vp] + [_c_int] * 5 + [_c_float, _vp, _c_int, _vp],
     "rdetr_relation_attention_boxes_bf16": [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_int] * 6 + [_c_float] * 4 + [_vp, _c_int, _vp],
@@ -42,6 +44,7 @@ SIGNATURES = {
     "rdetr_topk_workspace_bytes": [_c_int, _c_int, _c_int],
     "rdetr_topk": [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "rdetr_box_head_k256_bf16": [_vp, _c_ll, _vp, _c_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_float, _c_ll, _vp, _vp, _vp],
+    "rdetr_query_pos_k256_bf16": [_vp, _c_ll, _vp, _c_ll] + [_vp] * 9 + [_c_ll, _vp, _vp, _vp],
     "rdetr_detections_from_topk": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "rdetr_scaled_pos": [_vp, _vp, _vp, _c_ll, _c_int, _vp, _vp, _vp],
     "rdetr_decoder_reference": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _vp, _vp, _c_int, _vp],
@@ -81,7 +84,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "rdetr_status_string" else (_c_ll if name == "rdetr_topk_workspace_bytes" else _c_int)
+        fn.restype = ctypes.c_char_p if name == "rdetr_status_string" else (_c_ll if name.endswith("_workspace_bytes") else _c_int)
     if lib.rdetr_abi_version() != 3:
         raise RdetrError(f"ABI version mismatch: library {lib.rdetr_abi_version()}, binding 3")
     _lib = lib

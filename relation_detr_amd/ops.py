@@ -346,6 +346,36 @@ def relation_bias(src_boxes: torch.Tensor, tgt_boxes: torch.Tensor, proj_weight:
     return out
 
 
+def relation_bias_backward_supported(num_heads: int, num_pos_feats: int) -> bool:
+    return num_heads == 8 and num_pos_feats == 16
+
+
+def relation_bias_backward(src_boxes: torch.Tensor, tgt_boxes: torch.Tensor, grad_out: torch.Tensor, active: torch.Tensor,
+                           num_pos_feats: int = 16, temperature: float = 10000.0, scale: float = 100.0, eps: float = 1e-5):
+    """Gradients of ``relation_bias`` with respect to the projection: (grad_weight [Hh, 4F], grad_bias [Hh]) from the upstream
+    gradient ``grad_out`` [B,Hh,N1,N2] and the ReLU mask ``active`` (bool, forward output > 0) -- the sine features are
+    regenerated from the boxes inside the kernel (csrc/relation_bwd.hip), the reduction is deterministic.  Hh = 8, F = 16."""
+    _require_device(src_boxes, tgt_boxes, grad_out, active)
+    B, Hh, N1, N2 = grad_out.shape
+    if not relation_bias_backward_supported(Hh, num_pos_feats):
+        raise _lib.RdetrError("relation_bias_backward: 8 heads and 16 sine features per coordinate only")
+    if tuple(src_boxes.shape) != (B, N1, 4) or tuple(tgt_boxes.shape) != (B, N2, 4) or active.shape != grad_out.shape:
+        raise _lib.RdetrError("relation_bias_backward: src [B,N1,4], tgt [B,N2,4], grad_out / active [B,Hh,N1,N2]")
+    src, tgt = src_boxes.detach().float().contiguous(), tgt_boxes.detach().float().contiguous()
+    g = grad_out.detach().float().contiguous()
+    act = active.contiguous()
+    act = act.view(torch.uint8) if act.dtype == torch.bool else act.to(torch.uint8)
+    lib = _lib.load()
+    ws = torch.empty(max(int(lib.rdetr_relation_bias_backward_workspace_bytes(B, N1, N2)) // 4, 1), dtype=torch.float32, device=g.device)
+    gw = torch.empty(Hh, 4 * num_pos_feats, dtype=torch.float32, device=g.device)
+    gb = torch.empty(Hh, dtype=torch.float32, device=g.device)
+    st = lib.rdetr_relation_bias_backward_f32(src.data_ptr(), tgt.data_ptr(), g.data_ptr(), act.data_ptr(), B, N1, N2, Hh, num_pos_feats,
+                                              float(scale), float(temperature), float(eps), ws.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                              _stream_ptr(g))
+    _lib.check(st, "rdetr_relation_bias_backward_f32")
+    return gw, gb
+
+
 def bias_softmax_(scores: torch.Tensor, bias: Optional[torch.Tensor] = None,
                   mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """In place: scores[BH,N1,N2] <- softmax(scores + bias, -1); mask [N1,N2] bool, True = excluded."""
@@ -642,6 +672,61 @@ def box_head_k256(xa: torch.Tensor, xb: Optional[torch.Tensor], layers, referenc
         _stream_ptr(xa))
     _lib.check(st, "rdetr_box_head_k256_bf16")
     return out_a if xb is None else (out_a, out_b)
+
+
+def query_pos_k256_supported(emb: torch.Tensor, query: torch.Tensor, head_layers, scale_layers=None) -> bool:
+    def lin_ok(l, n_in):
+        return (tuple(l.weight.shape) == (256, n_in) and l.bias is not None and l.weight.dtype == torch.bfloat16
+                and l.bias.dtype == torch.bfloat16 and l.weight.is_contiguous() and l.weight.data_ptr() % 16 == 0)
+    if not (emb.is_cuda and emb.dtype == torch.bfloat16 and query.dtype == torch.bfloat16 and emb.shape[-1] == 512 and query.shape[-1] == 256
+            and emb.shape[:-1] == query.shape[:-1] and len(head_layers) == 2 and lin_ok(head_layers[0], 512) and lin_ok(head_layers[1], 256)):
+        return False
+    return scale_layers is None or (len(scale_layers) == 2 and lin_ok(scale_layers[0], 256) and lin_ok(scale_layers[1], 256))
+
+
+def _packed_k_halves(weight: torch.Tensor):
+    """The two K halves of a [256, 512] bf16 weight, each in fragment order; cached until the tensor changes or dies."""
+    def build():
+        halves = []
+        for h in range(2):
+            w = weight.detach()[:, 256 * h:256 * (h + 1)].contiguous()
+            packed = torch.empty(256 * 256, dtype=torch.bfloat16, device=weight.device)
+            st = _lib.load().rdetr_linear_pack_k256_bf16(w.data_ptr(), packed.data_ptr(), _stream_ptr(weight))
+            _lib.check(st, "rdetr_linear_pack_k256_bf16")
+            halves.append(packed)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(weight.device).synchronize()
+        return tuple(halves)
+    return _LINEAR_PACKED.get((weight,), build)
+
+
+def query_pos_k256(emb: torch.Tensor, query: torch.Tensor, head_layers, scale_layers=None):
+    """``(query_pos, query + query_pos)`` of a decoder layer in one kernel (csrc/qpos.hip): ``query_pos = ref_point_head(emb)``,
+    multiplied by ``query_scale(query)`` when ``scale_layers`` is given (relation_transformer.py:343-347).  emb [..., 512], query
+    [..., 256] bf16; head_layers / scale_layers: the two nn.Linear of each MLP.  Inference only."""
+    _require_device(emb, query)
+    if not query_pos_k256_supported(emb, query, head_layers, scale_layers):
+        raise _lib.RdetrError("query_pos_k256: bf16 emb [..., 512] / query [..., 256], Linear(512,256), Linear(256,256) (x2) in bf16 with biases")
+    if query.dim() == 3 and query.stride(0) == 0:
+        query = query.contiguous()                      # layer 0: tgt_embed.weight.expand(B, -1, -1) (relation_transformer.py:117)
+    rows, _, lde = _rows_view(emb, "query_pos_k256")
+    _, _, ldq = _rows_view(query, "query_pos_k256")
+    if lde % 8 or ldq % 8 or emb.data_ptr() % 16 or query.data_ptr() % 16:
+        raise _lib.RdetrError("query_pos_k256: rows must be 16-byte aligned")
+    p1a, p1b = _packed_k_halves(head_layers[0].weight)
+    p2 = _packed_k256(head_layers[1].weight)
+    sc = [None] * 4
+    if scale_layers is not None:
+        sc = [_packed_k256(scale_layers[0].weight).data_ptr(), scale_layers[0].bias.contiguous().data_ptr(),
+              _packed_k256(scale_layers[1].weight).data_ptr(), scale_layers[1].bias.contiguous().data_ptr()]
+    pos = torch.empty(*query.shape, dtype=torch.bfloat16, device=query.device)
+    qpp = torch.empty_like(pos)
+    st = _lib.load().rdetr_query_pos_k256_bf16(emb.data_ptr(), lde, query.data_ptr(), ldq, p1a.data_ptr(), p1b.data_ptr(),
+                                               head_layers[0].bias.contiguous().data_ptr(), p2.data_ptr(),
+                                               head_layers[1].bias.contiguous().data_ptr(), sc[0], sc[1], sc[2], sc[3], rows,
+                                               pos.data_ptr(), qpp.data_ptr(), _stream_ptr(query))
+    _lib.check(st, "rdetr_query_pos_k256_bf16")
+    return pos, qpp
 
 
 def topk_supported(x: torch.Tensor, k: int) -> bool:

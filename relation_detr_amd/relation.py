@@ -10,7 +10,8 @@ and ``pos_proj.0.bias [H]``.
 The reference materialises [B,N,N,4] -> [B,N,N,64] -> conv -> [B,8,N,N]; here a single kernel
 (``rdetr_relation_bias_f32``) goes from the boxes to the bias.  Boxes get no gradient (the
 reference wraps the encoding in ``torch.no_grad``, :527-529); ``pos_proj`` does, through a backward
-that recomputes the sine features with device torch ops (training only).
+kernel that regenerates the sine features from the boxes (``rdetr_relation_bias_backward_f32``, training only;
+other head / feature counts recompute them with device torch ops).
 """
 from __future__ import annotations
 
@@ -51,6 +52,11 @@ class _RelationBiasFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         src, tgt, active = ctx.saved_tensors
         F_, temperature, scale, wshape, has_bias = ctx.cfg
+        if ops.relation_bias_backward_supported(wshape[0], F_):
+            # one kernel: the features are regenerated from the boxes and reduced on the fly, deterministically
+            # (csrc/relation_bwd.hip) -- the reference's autograd keeps [N1, N2, 64] per image for this (207 MB at N = 900)
+            gw, gb = ops.relation_bias_backward(src, tgt, grad_out, active, F_, temperature, scale)
+            return None, None, gw.view(wshape), (gb if has_bias else None), None, None, None
         g = grad_out * active                                          # ReLU'
         gw = torch.zeros(wshape[0], 4 * F_, dtype=torch.float32, device=g.device)
         for b in range(src.shape[0]):                                  # one image at a time bounds the feature tensor

@@ -288,9 +288,16 @@ class RelationTransformerDecoder(nn.Module):
                     ratio_scale = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
                 ref_in = reference_points.detach()[:, :, None] * ratio_scale        # [B,N,L,4]
                 emb = sine_pos_embed(ref_in[:, :, 0, :], self.embed_dim // 2).to(query.dtype)
-            query_pos = self.ref_point_head(emb)
             qpp = None
-            if idx != 0:
+            scale_layers = None if idx == 0 else self.query_scale.layers
+            if (self.options.decoder_tail and query.is_cuda and not torch.is_grad_enabled() and emb.dtype == torch.bfloat16
+                    and ops.query_pos_k256_supported(emb, query, self.ref_point_head.layers, scale_layers)):
+                # bf16 inference: both MLPs, their product and query + query_pos in ONE launch (csrc/qpos.hip) instead of four
+                # GEMMs + one elementwise launch of the decoder's dependency chain
+                query_pos, qpp = ops.query_pos_k256(emb, query, self.ref_point_head.layers, scale_layers)
+            else:
+                query_pos = self.ref_point_head(emb)
+            if idx != 0 and qpp is None:
                 if query.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16) \
                         and query_pos.dtype == query.dtype and self.options.decoder_entry:
                     query_pos, qpp = ops.scaled_pos(query_pos, self.query_scale(query), query)      # the product and query + product

@@ -605,6 +605,52 @@ def test_fused_box_head_matches_the_unfused_sequence():
         assert (got_l - w).abs().max().item() <= 4e-3 and (got_l[0, 1] == 1.0).all()
 
 
+def test_fused_query_pos_matches_the_unfused_sequence():
+    """rdetr_query_pos_k256_bf16 (csrc/qpos.hip) against the decoder's own statements (relation_transformer.py:343-347, 452-455):
+    query_pos = ref_point_head(emb) [* query_scale(query)], qpp = query + query_pos -- four bf16 GEMMs with ReLU, a product and a
+    sum.  Reference arithmetic: fp32 products of the bf16 operands with every intermediate rounded to bf16 where the unfused path
+    stores it; also compared with the unfused torch sequence itself."""
+    from relation_detr_amd import ops
+    from relation_detr_amd.transformer import MLP
+    torch.manual_seed(7)
+    head = MLP(512, 256, 256, 2).to(DEV).to(torch.bfloat16)
+    scale = MLP(256, 256, 256, 2).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        for l in (*head.layers, *scale.layers):
+            l.bias.copy_(torch.randn(256) * 0.1)
+    g = torch.Generator().manual_seed(8)
+    bf = lambda t: t.to(torch.bfloat16).float()
+
+    def mlp(m, x):
+        h = bf((x.float() @ m.layers[0].weight.float().t() + m.layers[0].bias.float()).relu())
+        return bf(h @ m.layers[1].weight.float().t() + m.layers[1].bias.float())
+
+    for B, N in ((2, 900), (1, 37), (3, 301)):
+        emb = torch.randn(B, N, 512, generator=g).to(torch.bfloat16).to(DEV)
+        query = torch.randn(B, N, 256, generator=g).to(torch.bfloat16).to(DEV)
+        for scaled in (False, True):
+            pos, qpp = ops.query_pos_k256(emb, query, head.layers, scale.layers if scaled else None)
+            assert pos.dtype == torch.bfloat16 and pos.shape == query.shape and qpp.shape == query.shape
+            want = mlp(head, emb)
+            if scaled:
+                want = bf(want * mlp(scale, query))
+            # one bf16 rounding of a hidden unit can differ by an ulp with the summation order: 2^-7 of the output scale
+            tol = 2.0 ** -7 * want.abs().max().item()
+            assert (pos.float() - want).abs().max().item() <= tol and (pos.float() - want).abs().mean().item() <= tol / 16
+            assert torch.equal(qpp, (query.float() + pos.float()).to(torch.bfloat16))          # the sum of the kernel's own query_pos
+            with torch.no_grad():                                                               # the unfused torch sequence (library GEMMs)
+                t = head(emb)
+                if scaled:
+                    t = t * scale(query)
+            assert (pos.float() - t.float()).abs().max().item() <= tol
+    # layer 0's query is an expanded embedding (batch stride 0)
+    emb = torch.randn(2, 50, 512, generator=g).to(torch.bfloat16).to(DEV)
+    q0 = torch.randn(50, 256, generator=g).to(torch.bfloat16).to(DEV).expand(2, -1, -1)
+    pos, qpp = ops.query_pos_k256(emb, q0, head.layers, None)
+    assert (pos.float() - mlp(head, emb)).abs().max().item() <= 2.0 ** -7 * pos.float().abs().max().item()
+    assert torch.equal(qpp, (q0.float() + pos.float()).to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("rows,n,k", [(4, 22323, 900), (4, 81900, 300), (2, 22323, 900), (3, 5000, 1024), (1, 4096, 1), (2, 1500, 1500 - 476),
                                       (5, 33, 33)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -301,6 +301,44 @@ def test_relation_bias_backward_after_caller_mutates_output(rd):
     assert torch.isfinite(rel.pos_proj[0].weight.grad).all()
 
 
+@pytest.mark.parametrize("B,N1,N2", [(1, 300, 300), (2, 97, 515), (3, 33, 257)])
+def test_relation_bias_backward_kernel(rd, B, N1, N2):
+    """rdetr_relation_bias_backward_f32 (csrc/relation_bwd.hip) against autograd through the oracle's materialised features
+    (what the reference differentiates, relation_transformer.py:527-532) in DOUBLE precision: row / column tails on every
+    tile edge, a masked share of g, the same bits on a second run (the reduction is a fixed-order tree, no atomics)."""
+    from oracle import torch_ref
+    from relation_detr_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N1)
+    src = torch.cat([torch.rand(B, N1, 2, generator=g), torch.rand(B, N1, 2, generator=g) * 0.4 + 0.02], -1)
+    tgt = torch.cat([torch.rand(B, N2, 2, generator=g), torch.rand(B, N2, 2, generator=g) * 0.4 + 0.02], -1)
+    go = torch.randn(B, 8, N1, N2, generator=g)
+    active = torch.rand(B, 8, N1, N2, generator=g) < 0.6                       # the ReLU mask is an INPUT of the operator
+    gw, gb = ops.relation_bias_backward(src.to(DEV), tgt.to(DEV), go.to(DEV), active.to(DEV))
+    gw2, gb2 = ops.relation_bias_backward(src.to(DEV), tgt.to(DEV), go.to(DEV), active.to(DEV))
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    gm = (go * active).double()
+    want_w = torch.zeros(8, 64, dtype=torch.float64)
+    for b in range(B):                                                          # one image at a time bounds the feature tensor
+        feat = torch_ref.sine_embed(torch_ref.box_rel_encoding(src[b:b + 1].double(), tgt[b:b + 1].double()))[0]      # [N1, N2, 64]
+        want_w += torch.einsum("hij,ijc->hc", gm[b], feat)
+    want_b = gm.sum(dim=(0, 2, 3))
+    # fp32 features (angles up to 1e3 rad carry ~3e-5 rad of rounding) summed over up to 1e5 pairs per entry: 2e-3 of the
+    # root-sum-square of the terms, i.e. of sqrt(pairs), is the bound the module-level tests use as well
+    scale = float(np.sqrt(B * N1 * N2))
+    np.testing.assert_allclose(gw.cpu().numpy(), want_w.numpy(), rtol=1e-4, atol=2e-3 * scale / 30)
+    np.testing.assert_allclose(gb.cpu().numpy(), want_b.numpy(), rtol=1e-5, atol=1e-3)
+
+
+def test_relation_bias_backward_kernel_empty_and_errors(rd):
+    from relation_detr_amd import _lib, ops
+    z = torch.zeros(2, 8, 0, 5, device=DEV)
+    gw, gb = ops.relation_bias_backward(torch.zeros(2, 0, 4, device=DEV), torch.rand(2, 5, 4, device=DEV), z, z > 0)
+    assert gw.shape == (8, 64) and not gw.any() and not gb.any()
+    with pytest.raises(_lib.RdetrError):
+        ops.relation_bias_backward(torch.rand(1, 4, 4, device=DEV), torch.rand(1, 4, 4, device=DEV), torch.zeros(1, 4, 4, 4, device=DEV),
+                                   torch.zeros(1, 4, 4, 4, dtype=torch.bool, device=DEV))
+
+
 # ------------------------------------------------------------------------------------------ bias softmax / self-attention
 @pytest.mark.parametrize("BH,N1,N2", [(8, 50, 50), (16, 300, 300), (8, 37, 901), (2, 5, 1100), (1, 3, 5000), (4, 900, 900)])
 def test_bias_softmax_vs_torch(rd, BH, N1, N2):

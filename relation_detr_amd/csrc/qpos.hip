@@ -5,13 +5,19 @@
 // i.e. four library GEMMs of 1,800 rows + the product / sum launch of the decoder's dependency chain (~6 us each whatever their
 // size, and the two MLPs are independent branches a single stream serialises) in one launch.
 //
-//   workgroup  512 threads = 8 waves x 16 rows (rows are the unit of parallelism: a row needs all 256 hidden units)
+//   workgroup  4 waves x 16 rows (rows are the unit of parallelism: a row needs all 256 hidden units; every wave reads the whole
+//              weight half from LDS per phase, so more waves per workgroup only queue on the LDS: 8 waves 28.5 us, 4 waves see
+//              tools/time_qpos.py)
 //   layers     chained INSIDE the wave with the output permutation of csrc/ffn.hip / csrc/mlp.hip: after tile pair u lane
 //              (row, g) holds outputs 32 u + 8 g .. + 7 of its row, which -- biased, ReLU'd, rounded to bf16 as the unfused path
 //              stores them -- ARE the B operand of the next layer's k-step u.  Nothing changes lanes.
 //   weights    five [256, 256] blocks packed in fragment order (rdetr_linear_pack_k256_bf16; the 512-input layer as its two
-//              K halves), streamed L2 -> LDS by LDS-DMA in 64-KiB halves through two buffers: the half for phase i + 1 is
-//              issued as soon as every wave has left the buffer it overwrites, i.e. behind phase i's MFMAs.
+//              K halves), streamed in 64-KiB halves: the half for phase i + 1 is loaded into REGISTERS (16 coalesced 1-KiB loads
+//              per wave) behind phase i's MFMAs and written to the one LDS buffer once every wave has left it.
+//   measured   (tools/time_qpos.py, 1,800 rows, graph replay) 21.7 us against 22.6 us for the five launches it replaces; component
+//              builds: without the MFMAs 21.5, without the LDS fragment reads 17.4, without the weight stream 14.1 -- a workgroup
+//              pulls all 640 KB of weights through its CU's 64 B/clk vector-memory path (4.7 us) and through LDS twice, phase by
+//              phase, so the chain cannot shrink much further; +1 % images/s in the stack (profiles/r03/ab_stack_query_pos.txt).
 //   rounding   every intermediate is rounded where the unfused bf16 path stores it (hidden activations, query_pos, the scale, their
 //              product), so the result is the unfused sequence's up to the summation order inside a dot product.
 #include "common.h"
@@ -22,9 +28,10 @@ namespace {
 
 typedef __bf16 qp_bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kQpThreads = 512, kQpWaves = 8, kQpRows = 16;
+constexpr int kQpWaves = 4, kQpThreads = kQpWaves * 64, kQpRows = 16;        // 64 rows per workgroup: 29 workgroups at 1,800 rows
+constexpr int kQpFragsPerWave = 64 / kQpWaves;                                 // LDS-DMA instructions per wave and weight half
 constexpr int kQpHalf = 8 * 8 * 64 * 16;                  // 64 KiB: 8 tiles x 8 k-steps of 1-KiB fragments
-constexpr int kQpLdsBias = 2 * kQpHalf;                   // b1 | b2 | c1 | c2 as fp32
+constexpr int kQpLdsBias = kQpHalf;                       // one weight half, then b1 | b2 | c1 | c2 as fp32
 constexpr int kQpLdsBytes = kQpLdsBias + 4 * 256 * 4;
 
 __global__ __launch_bounds__(kQpThreads) void query_pos_k256_kernel(
@@ -40,35 +47,32 @@ __global__ __launch_bounds__(kQpThreads) void query_pos_k256_kernel(
     const int col = lane & 15, g = lane >> 4;
     const bool scaled = pv1 != nullptr;                                       // uniform: layers >= 1
 
-    // half h (output tiles 8 h .. 8 h + 7) of a packed [256, 256] block -> LDS buffer `buf`: 64 fragments, 8 per wave
-    auto issue_half = [&](const uint16_t *packed, int h, int buf) {
-        const unsigned lane_off = (unsigned)lane * 16u;
+    // half h (output tiles 8 h .. 8 h + 7) of a packed [256, 256] block: 64 fragments of 1 KiB dealt over the waves.  `fetch`
+    // brings this wave's share into REGISTERS (coalesced 1-KiB loads, in flight behind the current phase's MFMAs); `commit` moves
+    // it into the LDS buffer once every wave has left that buffer.  (LDS-DMA would save the registers, but each DMA instruction
+    // costs 100-350 cycles of issue behind its M0 write: with 16 of them per wave and phase the kernel took 25-28 us.)
+    // One register set, fetched one phase ahead (a second set, two phases ahead, measured the same and spilled).
+    u32x4 stg[kQpFragsPerWave];
+    auto fetch = [&](const uint16_t *packed, int h) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = wave * 8 + i;                                       // uniform
-            const unsigned m0v = (unsigned)(buf * kQpHalf + f * 1024);
-            const unsigned char *src = reinterpret_cast<const unsigned char *>(packed) + (size_t)h * kQpHalf + f * 1024;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(lane_off), "s"(src) : "memory", "m0");
-        }
+        for (int i = 0; i < kQpFragsPerWave; ++i)
+            stg[i] = reinterpret_cast<const u32x4 *>(packed)[((size_t)h * kQpHalf + (size_t)(wave * kQpFragsPerWave + i) * 1024) / 16 + lane];
+        __builtin_amdgcn_sched_barrier(0);                                    // the loads are issued HERE, ahead of the phase's MFMAs
     };
-    // the buffer filled before the most recent issue_half has landed for THIS wave (vmcnt counts in issue order: the 8 youngest
-    // operations are the newer half's), then for all waves
-    auto publish_older = [&]() {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __syncthreads();
-    };
-    auto publish_all = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    auto commit = [&]() {
+        __syncthreads();                                                      // every wave has left the buffer
+        u32x4 *dst = reinterpret_cast<u32x4 *>(qp_lds);
+#pragma unroll
+        for (int i = 0; i < kQpFragsPerWave; ++i) dst[(wave * kQpFragsPerWave + i) * 64 + lane] = stg[i];
+        __syncthreads();                                                      // ... and sees the new half
     };
 
-    issue_half(pw1a, 0, 0);
-    issue_half(pw1b, 0, 1);
-    if (tid < 256) {
-        bl[tid] = bf16_bits_to_f32(b1[tid]);
-        bl[256 + tid] = bf16_bits_to_f32(b2[tid]);
-        bl[512 + tid] = scaled ? bf16_bits_to_f32(c1[tid]) : 0.f;
-        bl[768 + tid] = scaled ? bf16_bits_to_f32(c2[tid]) : 0.f;
+    fetch(pw1a, 0);
+    for (int i = tid; i < 256; i += kQpThreads) {
+        bl[i] = bf16_bits_to_f32(b1[i]);
+        bl[256 + i] = bf16_bits_to_f32(b2[i]);
+        bl[512 + i] = scaled ? bf16_bits_to_f32(c1[i]) : 0.f;
+        bl[768 + i] = scaled ? bf16_bits_to_f32(c2[i]) : 0.f;
     }
     const long long row = ((long long)blockIdx.x * kQpWaves + wave) * kQpRows + col;
     const bool rok = row < M;
@@ -81,15 +85,22 @@ __global__ __launch_bounds__(kQpThreads) void query_pos_k256_kernel(
     auto mm = [&](const u32x4 &a, const u32x4 &bq, const f32x4 &c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(qp_bf16x8, a), __builtin_bit_cast(qp_bf16x8, bq), c, 0, 0, 0);
     };
-    // acc[uu][e] += (tile pair uu of the half in `buf`) x xin: 4 pairs x 2 tiles x 8 k-steps
-    auto pairs = [&](int buf, const u32x4 *xin, f32x4 (&acc)[4][2]) {
-        const u32x4 *w = wl + buf * (kQpHalf / 16);
+    // acc[uu][e] += (tile pair uu of the half in LDS) x xin: 4 pairs x 8 k-steps x 2 tiles = 64 fragments, read as ONE stream
+    // through a ring of four registers, three fragments ahead of their MFMA (left to itself hipcc reads every fragment into the
+    // same register right before its MFMA and waits lgkmcnt(0): the full LDS latency 64 times per phase -- 2.9 us per phase)
+    auto pairs = [&](int, const u32x4 *xin, f32x4 (&acc)[4][2]) {
+        constexpr int kFrags = 64, kAhead = 3;          // deeper (7 ahead) measured the same
+        u32x4 ring[4];
+        auto frag = [&](int f) { return wl[(((2 * (f >> 4) + (f & 1)) * 8 + ((f >> 1) & 7)) * 64) + lane]; };
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu)
+        for (int f = 0; f < kAhead; ++f) ring[f & 3] = frag(f);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) acc[uu][e] = mm(w[((2 * uu + e) * 8 + s) * 64 + lane], xin[s], acc[uu][e]);
+        for (int f = 0; f < kFrags; ++f) {
+            if (f + kAhead < kFrags) ring[(f + kAhead) & 3] = frag(f + kAhead);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[f >> 4][f & 1] = mm(ring[f & 3], xin[(f >> 1) & 7], acc[f >> 4][f & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     auto zero = [&](f32x4 (&acc)[4][2]) {
 #pragma unroll
@@ -111,64 +122,55 @@ __global__ __launch_bounds__(kQpThreads) void query_pos_k256_kernel(
     f32x4 acc[4][2];
     u32x4 y1[8], pos[8];
     // ---- layer 1 of ref_point_head: K = 512 = two packed blocks ------------------------------------------------------------
-    publish_all();                                                            // W1a.h0 -> buf 0, W1b.h0 -> buf 1, biases
+    // phase i: fetch the half of phase i + 1 | MFMAs on the half in LDS | commit
+    commit();                                                                 // W1a.h0 (and the biases)
+    fetch(pw1b, 0);
     zero(acc);
     pairs(0, xe, acc);
-    __syncthreads();                                                          // every wave has left buf 0
-    issue_half(pw1a, 1, 0);
-    pairs(1, xe + 8, acc);
+    commit();                                                                 // W1b.h0
+    fetch(pw1a, 1);
+    pairs(0, xe + 8, acc);
     finish(acc, bl, 0, true, y1);
-    __syncthreads();                                                          // ... and buf 1
-    issue_half(pw1b, 1, 1);
-    publish_older();                                                          // W1a.h1 landed
+    commit();                                                                 // W1a.h1
+    fetch(pw1b, 1);
     zero(acc);
     pairs(0, xe, acc);
-    __syncthreads();
-    issue_half(pw2, 0, 0);
-    publish_older();                                                          // W1b.h1 landed
-    pairs(1, xe + 8, acc);
+    commit();                                                                 // W1b.h1
+    fetch(pw2, 0);
+    pairs(0, xe + 8, acc);
     finish(acc, bl, 1, true, y1);
-    __syncthreads();
-    issue_half(pw2, 1, 1);
-    publish_older();                                                          // W2.h0 landed
+    commit();                                                                 // W2.h0
     // ---- layer 2 of ref_point_head ---------------------------------------------------------------------------------------
+    fetch(pw2, 1);
     zero(acc);
     pairs(0, y1, acc);
     finish(acc, bl + 256, 0, false, pos);
-    if (scaled) {
-        __syncthreads();
-        issue_half(pv1, 0, 0);
-        publish_older();                                                      // W2.h1 landed
-    } else {
-        publish_all();
-    }
+    commit();                                                                 // W2.h1
+    if (scaled) fetch(pv1, 0);
     zero(acc);
-    pairs(1, y1, acc);
+    pairs(0, y1, acc);
     finish(acc, bl + 256, 1, false, pos);
     if (scaled) {
         // ---- query_scale(query), then the product -----------------------------------------------------------------------
         u32x4 sc[8];
-        __syncthreads();
-        issue_half(pv1, 1, 1);
-        publish_older();                                                      // V1.h0 landed
+        commit();                                                             // V1.h0
+        fetch(pv1, 1);
         zero(acc);
         pairs(0, xq, acc);
         finish(acc, bl + 512, 0, true, y1);
-        __syncthreads();
-        issue_half(pv2, 0, 0);
-        publish_older();                                                      // V1.h1 landed
+        commit();                                                             // V1.h1
+        fetch(pv2, 0);
         zero(acc);
-        pairs(1, xq, acc);
+        pairs(0, xq, acc);
         finish(acc, bl + 512, 1, true, y1);
-        __syncthreads();
-        issue_half(pv2, 1, 1);
-        publish_older();                                                      // V2.h0 landed
+        commit();                                                             // V2.h0
+        fetch(pv2, 1);
         zero(acc);
         pairs(0, y1, acc);
         finish(acc, bl + 768, 0, false, sc);
-        publish_all();                                                        // V2.h1 landed
+        commit();                                                             // V2.h1
         zero(acc);
-        pairs(1, y1, acc);
+        pairs(0, y1, acc);
         finish(acc, bl + 768, 1, false, sc);
         // query_pos * scale, rounded to bf16 as torch's bf16 multiply (fp32 product of the two bf16 values, one rounding)
 #pragma unroll

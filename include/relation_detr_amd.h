@@ -141,6 +141,18 @@ int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int value_layout, c
                                       const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
                                       int algo, uint16_t *out, void *stream);
 
+/* The fused-producer bf16 operator on a ROW-STRIDED value: pixel s of image b starts at value + (b * S + s) * value_ld elements
+ * (value_ld >= H * D, a 16-byte multiple; 0 = dense), i.e. `value` may be a 256-column slice of a wider projection output.  Lets
+ * the SIX cross-attention value projections of the decoder (models/bricks/relation_transformer.py:464-471 calls value_proj of
+ * each layer on the same encoder memory, ms_deform_attn.py:316) run as ONE [S, 256] x [256, 6*256] GEMM whose output each
+ * layer's gather reads in place.  [B,S,H,D] layout, direct kernel, fast-path shapes; other arguments as
+ * rdetr_msda_forward_fused_ex_bf16. */
+int rdetr_msda_forward_fused_strided_bf16(const uint16_t *value, long long value_ld, const int64_t *spatial_shapes,
+                                          const int64_t *level_start_index, const uint16_t *sampling_offsets, int ld_offsets,
+                                          const uint16_t *attn_logits, int ld_logits, const float *reference_points, int ref_dim,
+                                          const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq, int P,
+                                          uint16_t *out, void *stream);
+
 /* Projected value [B, S, H*D] bf16 (rows `ld` elements apart, ld % 8 == 0: the rows may be a column slice of a wider
  * buffer) -> head-major [B, H, S, D], with the rows of padded positions (`key_padding_mask` u8 [B, S], may be NULL)
  * written as zeros -- the zero-fill of models/bricks/ms_deform_attn.py:316-319 folded into the re-layout.  H = 8, D = 32. */

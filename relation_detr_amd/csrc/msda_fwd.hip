@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
     int L_rt, int Nq, int tiles_per_image, int nblk, T *__restrict__ out,
-    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major)
+    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major, int value_pix_bytes)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
@@ -261,12 +261,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
 
     // value [B,S,H,D] (the reference operator's layout: a pixel's heads side by side) or, head_major, [B,H,S,D]: either way
     // the (image, head) plane sits behind one wave-uniform buffer descriptor and a pixel step is `pixb` bytes
-    const unsigned pixb = head_major ? IO::kHeadBytes : IO::kPixelBytes;
+    // (`value_pix_bytes` = bytes from one pixel to the next in [B,S,H,D]: H*D*sizeof(T) for a dense tensor, more when the rows
+    // are a column slice of a wider projection output -- the decoder's six cross-attention value projections as ONE GEMM)
+    const unsigned pixb = head_major ? IO::kHeadBytes : (unsigned)value_pix_bytes;
     const __amdgpu_buffer_rsrc_t rsrc =
         head_major ? __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value) + ((size_t)b * kHeads + m) * (size_t)S * kHeadDim, 0,
                                                        (unsigned)S * IO::kHeadBytes, 0x00020000)
-                   : __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(value) + (size_t)b * S * (kHeads * kHeadDim) + m * kHeadDim, 0,
-                                                       (unsigned)S * IO::kPixelBytes - (unsigned)m * IO::kHeadBytes, 0x00020000);
+                   : __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char *>(const_cast<T *>(value)) +
+                                                           (size_t)b * S * (size_t)pixb + (size_t)m * IO::kHeadBytes,
+                                                       0, (unsigned)S * pixb - (unsigned)m * IO::kHeadBytes, 0x00020000);
     const unsigned lane_off = (unsigned)sub * 16u;
 
     u32x4 *soff = stage_off[wave];
@@ -530,7 +533,7 @@ template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
                         int S, int L, int Nq, int tiles, int nblk, T *out, const unsigned char *pad_mask, int ld_a, int ld_b,
-                        int head_major)
+                        int head_major, int value_pix_bytes)
 {
     // the 4-level kernel reads a lane's share of the query-side inputs as 16-byte vectors
     const bool vec_ok = reinterpret_cast<uintptr_t>(src_a) % 16 == 0 && reinterpret_cast<uintptr_t>(src_b) % 16 == 0 &&
@@ -538,13 +541,13 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
                                     (ld_b * (int)sizeof(T)) % 16 == 0));
     if (L == 4 && vec_ok)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
     else if (L == 5)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
     else
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
@@ -555,7 +558,7 @@ template <typename T, bool FUSED>
 static int msda_forward(const T *value, int layout, const int64_t *shapes, const int64_t *level_start, const void *src_a,
                         const void *src_b, const float *ref, int ref_dim, int B, int S, int H, int D, int L, int Nq,
                         int P, T *out, hipStream_t stream, int algo = RDETR_MSDA_AUTO, const unsigned char *pad_mask = nullptr,
-                        int ld_a = 0, int ld_b = 0)
+                        int ld_a = 0, int ld_b = 0, long long value_ld = 0)
 {
     if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
     if (layout != RDETR_VALUE_BSHD && layout != RDETR_VALUE_BHSD) return RDETR_ERR_INVALID_ARG;
@@ -567,7 +570,9 @@ static int msda_forward(const T *value, int layout, const int64_t *shapes, const
     if (S == 0) return RDETR_ERR_INVALID_ARG;
     const bool hm = layout == RDETR_VALUE_BHSD;
 
-    const long long pixel_bytes = (long long)H * D * (long long)sizeof(T);
+    // value_ld (elements, [B,S,H,D] only): row stride of a value tensor whose pixels are column slices of a wider buffer; 0 = dense
+    if (value_ld && (hm || value_ld < (long long)H * D || (value_ld * (long long)sizeof(T)) % 16 != 0)) return RDETR_ERR_INVALID_ARG;
+    const long long pixel_bytes = (value_ld ? value_ld : (long long)H * D) * (long long)sizeof(T);
     const bool aligned = (reinterpret_cast<uintptr_t>(value) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(src_a) % 8 == 0) && (reinterpret_cast<uintptr_t>(src_b) % 4 == 0);
     if (fast_path(H, D, L, P) && aligned && (long long)S * pixel_bytes < (1ll << 31)) {
@@ -577,7 +582,7 @@ static int msda_forward(const T *value, int layout, const int64_t *shapes, const
             // and cannot be checked here: plain AUTO therefore never takes it.  AUTO_PACKED (the caller has checked the table,
             // rdetr_msda_levels_window_ok) takes it for the reference operator's layout (measured at BASELINE.json configs[1]:
             // 127-132 us vs 141 us direct) and the direct kernel for the head-major one (118 us direct vs 127 us window).
-            if ((algo == RDETR_MSDA_WINDOW || (algo == RDETR_MSDA_AUTO_PACKED && !hm)) && !pad_mask) {
+            if ((algo == RDETR_MSDA_WINDOW || (algo == RDETR_MSDA_AUTO_PACKED && !hm)) && !pad_mask && !value_ld) {
                 const int st = hm ? msda_win_forward<FUSED, true>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B, S,
                                                                   L, Nq, ld_a, ld_b, out, stream)
                                   : msda_win_forward<FUSED, false>(value, shapes, level_start, src_a, src_b, ref, ref_dim, B,
@@ -592,10 +597,11 @@ static int msda_forward(const T *value, int layout, const int64_t *shapes, const
         const long long nblk = (long long)B * H * tiles;
         if (nblk > 0x7fffffffll) return RDETR_ERR_UNSUPPORTED;
         launch_qrun<T, FUSED>(dim3((unsigned)nblk), dim3(kWavesPerBlock * kWave), stream, value, shapes, level_start,
-                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, out, pad_mask, ld_a, ld_b, hm ? 1 : 0);
+                              src_a, src_b, ref, ref_dim, S, L, Nq, (int)tiles, (int)nblk, out, pad_mask, ld_a, ld_b, hm ? 1 : 0,
+                              (int)pixel_bytes);
         return launch_status();
     }
-    if (FUSED || pad_mask || ld_a || ld_b || hm || algo == RDETR_MSDA_WINDOW)
+    if (FUSED || pad_mask || ld_a || ld_b || hm || value_ld || algo == RDETR_MSDA_WINDOW)
         return RDETR_ERR_UNSUPPORTED;      // callers fall back to producing loc / weights themselves
     const long long total = (long long)B * Nq * H * D;
     const long long want = (total + 255) / 256;
@@ -749,6 +755,23 @@ extern "C" int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int valu
     return rdetr::msda_forward<uint16_t, true>(value, value_layout, spatial_shapes, level_start_index, sampling_offsets,
                                                attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
                                                static_cast<hipStream_t>(stream), algo, key_padding_mask, ld_offsets, ld_logits);
+}
+
+// Fused-producer form on a ROW-STRIDED value [B,S,H,D]: pixel s of image b starts at value + (b * S + s) * value_ld elements
+// (value_ld >= H*D, 16-byte multiple).  Direct kernel.
+extern "C" int rdetr_msda_forward_fused_strided_bf16(const uint16_t *value, long long value_ld, const int64_t *spatial_shapes,
+                                                     const int64_t *level_start_index, const uint16_t *sampling_offsets, int ld_offsets,
+                                                     const uint16_t *attn_logits, int ld_logits, const float *reference_points,
+                                                     int ref_dim, const uint8_t *key_padding_mask, int B, int S, int H, int D, int L, int Nq,
+                                                     int P, uint16_t *out, void *stream)
+{
+    if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
+        ld_offsets % 2 != 0 || value_ld < 0)
+        return RDETR_ERR_INVALID_ARG;
+    return rdetr::msda_forward<uint16_t, true>(value, RDETR_VALUE_BSHD, spatial_shapes, level_start_index, sampling_offsets,
+                                               attn_logits, reference_points, ref_dim, B, S, H, D, L, Nq, P, out,
+                                               static_cast<hipStream_t>(stream), RDETR_MSDA_DIRECT, key_padding_mask, ld_offsets,
+                                               ld_logits, value_ld);
 }
 
 extern "C" int rdetr_value_to_head_major_bf16(const uint16_t *src, long long ld, const uint8_t *key_padding_mask, int B, int S,

@@ -136,12 +136,15 @@ class MultiScaleDeformableAttention(nn.Module):
         return v, sampling_locations(reference_points, offsets, spatial_shapes, self.num_points), weights
 
     def forward(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
-                level_start_index: Tensor, key_padding_mask: Tensor, post_norm=None) -> Tensor:
+                level_start_index: Tensor, key_padding_mask: Tensor, post_norm=None, projected_value: Tensor = None) -> Tensor:
         """query [B,Nq,C]; reference_points [B,Nq,L,2] or [B,Nq,L,4]; value [B,S,C]; spatial_shapes
         [L,2] (h,w); level_start_index [L]; key_padding_mask [B,S] bool or None -> [B,Nq,C].
         ``post_norm = (residual, layer_norm)`` (not in the reference's signature, optional): return
         ``layer_norm(residual + output)`` -- the caller's next two steps (relation_transformer.py:270-271) -- which tall bf16
-        inference inputs get from the output projection's own epilogue (csrc/linear.hip)."""
+        inference inputs get from the output projection's own epilogue (csrc/linear.hip).
+        ``projected_value`` (not in the reference's signature, optional; bf16 inference): ``value_proj(value)`` WITHOUT the padding
+        fill, already computed by the caller -- a [B,S,C] view that may be a column slice of a wider buffer (the decoder runs the
+        value projections of its six layers as one GEMM, transformer.py).  Ignored unless the fused kernel path applies."""
         if value.is_cuda:      # same consistency check as the reference (:313), from a cached host copy
             shapes, _ = ops.host_levels(spatial_shapes, level_start_index)
             assert sum(h * w for h, w in shapes) == value.shape[1]
@@ -164,9 +167,14 @@ class MultiScaleDeformableAttention(nn.Module):
         # ... written by the value projection itself where the hand-written projection kernel applies (csrc/linear.hip)
         proj_hm = (head_major and self.options.value_proj_hm and self.value_proj.bias is not None
                    and self.value_proj.bias.dtype == torch.bfloat16 and ops.linear_k256_supported(value, self.value_proj.weight))
+        pre = (projected_value is not None and fused and not head_major and value.dtype == torch.bfloat16
+               and (key_padding_mask is None or mask_in_kernel) and projected_value.dtype == torch.bfloat16
+               and tuple(projected_value.shape) == tuple(value.shape))
         v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not (mask_in_kernel or head_major),
                                               merged=fused and self.options.merged_proj,
-                                              want_value=not proj_hm)
+                                              want_value=not (proj_hm or pre))
+        if pre:
+            v = projected_value.view(*value.shape[:2], self.num_heads, self.embed_dim // self.num_heads)
         vdt = value.dtype if proj_hm else v.dtype
         core_dtype = vdt if vdt in (torch.float32, torch.bfloat16) else torch.float32
         needs_grad = torch.is_grad_enabled() and any(
@@ -182,7 +190,7 @@ class MultiScaleDeformableAttention(nn.Module):
             # inference: softmax + location arithmetic happen inside the gather kernel's set-up phase, and so does the
             # padding mask (rows of padded positions count as zero: no fill pass over the projected value)
             core = ops.ms_deform_attn_forward_fused(
-                v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype),
+                v if pre else v.to(core_dtype).contiguous(), spatial_shapes, level_start_index, offsets.to(core_dtype),
                 logits.to(core_dtype), reference_points.float().contiguous(),
                 key_padding_mask if mask_in_kernel else None)
         elif (v.is_cuda and not needs_grad

@@ -215,8 +215,16 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         sampling_offsets, ld_off = sampling_offsets.contiguous(), 0
     if ld_lg is None:
         attn_logits, ld_lg = attn_logits.contiguous(), 0
-    _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                        reference_points=reference_points)
+    # a [B,S,H,D] bf16 value may be row-strided: the 256-column slice of a wider projection output (pixel stride in elements)
+    value_ld = 0
+    if (value.dim() == 4 and not value.is_contiguous() and value_layout == "bshd" and value.dtype == torch.bfloat16
+            and value.stride(3) == 1 and value.stride(2) == value.shape[3] and value.stride(1) >= value.shape[2] * value.shape[3]
+            and value.stride(1) % 8 == 0 and (value.shape[0] == 1 or value.stride(0) == value.shape[1] * value.stride(1))
+            and value.data_ptr() % 16 == 0 and algo in ("auto", "direct")):
+        value_ld = value.stride(1)
+    else:
+        _require_contiguous(value=value)
+    _require_contiguous(spatial_shapes=spatial_shapes, level_start_index=level_start_index, reference_points=reference_points)
     if value.dim() != 4 or sampling_offsets.dim() != 6 or reference_points.dim() != 4:
         raise _lib.RdetrError("expected value [B,S,H,D], sampling_offsets [B,Nq,H,L,P,2], reference_points [B,Nq,L,2|4]")
     B, S, H, D = _value_dims(value, value_layout)
@@ -246,6 +254,13 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
             else key_padding_mask.to(torch.uint8).contiguous()
         mask_ptr = mask_u8.data_ptr()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if value_ld:
+        st = lib.rdetr_msda_forward_fused_strided_bf16(
+            value.data_ptr(), value_ld, spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(), ld_off,
+            attn_logits.data_ptr(), ld_lg, reference_points.data_ptr(), ref_dim, mask_ptr, B, S, H, D, L, Nq, P, out.data_ptr(),
+            _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_fused_strided_bf16")
+        return out
     if value.dtype == torch.bfloat16:
         st = lib.rdetr_msda_forward_fused_opt_bf16(
             value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, spatial_shapes.data_ptr(),

@@ -28,7 +28,9 @@ class Options:
     ln_pos: bool = True              # encoder: norm2 also emits the next layer's query + pos
     decoder_ln_pos: bool = True      # decoder: norm2 also emits the cross-attention's query + query_pos
     decoder_entry: bool = True       # decoder layer entry (reference scaling + sine embedding, scaled query_pos) as 2 kernels
-    decoder_tail: bool = True        # reference-point head + query scale + product, FFN + norm3 as latency-optimised kernels
+    decoder_tail: bool = True        # reference-point head + query scale + product + query sum as one kernel (csrc/qpos.hip)
+    decoder_value_batched: bool = False  # the six cross-attention value projections as ONE GEMM ahead of the decoder's chain
+                                         # (opt-in: -1 % in the two-group replay, profiles/r03/ab_stack_decoder_value_batched_null_result.txt)
     box_head: bool = True            # box head + refinement as one kernel (csrc/mlp.hip)
     rel_fused: bool = True           # relation bias generated inside the attention kernel (csrc/attn_rel.hip)
     pyramid_points: bool = True      # valid ratios / reference points / proposal logits as two kernels

@@ -228,8 +228,9 @@ class RelationTransformerDecoderLayer(nn.Module):
         nn.init.xavier_uniform_(self.linear2.weight)
 
     def forward(self, query, query_pos, reference_points, value, spatial_shapes, level_start_index, self_attn_mask=None,
-                key_padding_mask=None, query_plus_pos=None):
-        """``query_plus_pos`` (not in the reference's signature, optional): ``query + query_pos`` if the caller already has it."""
+                key_padding_mask=None, query_plus_pos=None, projected_value=None):
+        """``query_plus_pos`` (not in the reference's signature, optional): ``query + query_pos`` if the caller already has it;
+        ``projected_value``: ``cross_attn.value_proj(value)`` if the caller already has it (see the decoder)."""
         qp = query + query_pos if query_plus_pos is None else query_plus_pos
         attn = self.self_attn(query=qp, key=qp, value=query, attn_mask=self_attn_mask, need_weights=False)[0]
         if (query.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16)
@@ -241,7 +242,8 @@ class RelationTransformerDecoderLayer(nn.Module):
             cross_q = query + query_pos
         cross = self.cross_attn(query=cross_q, reference_points=reference_points, value=value,
                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                                key_padding_mask=key_padding_mask)
+                                key_padding_mask=key_padding_mask,
+                                **({} if projected_value is None else {"projected_value": projected_value}))
         query = add_norm(self.norm1, query, cross)
         return add_norm(self.norm3, query, feed_forward(self.linear1, self.linear2, query, self.options))
 
@@ -270,6 +272,28 @@ class RelationTransformerDecoder(nn.Module):
             nn.init.zeros_(head.layers[-1].weight)
             nn.init.zeros_(head.layers[-1].bias)
 
+    def _batched_value_projection(self, value: Tensor):
+        """``cross_attn.value_proj(value)`` of ALL layers as one GEMM: [B,S,C] x [C, layers*C] -> [B,S,layers*C]; layer l reads its
+        column slice in place (csrc/msda_fwd.hip takes the pixel stride).  The reference runs the six projections one per layer
+        on the same encoder memory (relation_transformer.py:464-471 -> ms_deform_attn.py:316); batched they are one chip-filling
+        launch ahead of the decoder's chain of small launches instead of six launches on it.  OPT-IN (options.decoder_value_batched):
+        measured 1 % SLOWER in the two-group replay (978 vs 988 images/s, same box) -- on one stream the one GEMM is as long as
+        the six it replaces, and a 100-us chip-filling launch holds up the other image group where six 22-us ones interleave
+        with its small launches; it pays only where the projections can run BESIDE the chain.  The weights stay owned by the
+        layers' nn.Linear modules (state_dict keys unchanged); the concatenation is cached until one of them changes."""
+        projs = [layer.cross_attn.value_proj for layer in self.layers]
+        key = tuple((p.weight._version, p.bias._version, p.weight.data_ptr(), p.weight.dtype) for p in projs)
+        cache = getattr(self, "_value_proj_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, torch.cat([p.weight for p in projs], 0).contiguous(), torch.cat([p.bias for p in projs], 0).contiguous())
+            if value.is_cuda and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(value.device).synchronize()         # other streams (image groups) use it without an event
+            object.__setattr__(self, "_value_proj_cache", cache)
+        B, S, C = value.shape
+        v2 = value if value.is_contiguous() else value.contiguous()
+        return F.linear(v2.view(B * S, C), cache[1], cache[2]).view(B, S, len(projs) * C)
+
     def forward(self, query, reference_points, value, spatial_shapes, level_start_index, valid_ratios,
                 key_padding_mask=None, attn_mask=None, skip_relation=False):
         classes: List[Tensor] = []
@@ -277,6 +301,13 @@ class RelationTransformerDecoder(nn.Module):
         ratio_scale = None                                                          # [B,1,L,4], built when the torch path needs it
         pos_relation = attn_mask
         tgt_boxes = None
+        values_all = None
+        if (self.options.decoder_value_batched and value.is_cuda and not torch.is_grad_enabled() and value.dtype == torch.bfloat16
+                and query.shape[1] * 4 <= value.shape[1] and value.shape[-1] == self.embed_dim
+                and all(type(l.cross_attn).forward is MultiScaleDeformableAttention.forward and l.cross_attn.value_proj.bias is not None
+                        for l in self.layers)
+                and ops.msda_fast_path(self.num_heads, self.embed_dim // self.num_heads, spatial_shapes.shape[0], 4)):
+            values_all = self._batched_value_projection(value)                  # [B, S, layers * C]
         for idx, layer in enumerate(self.layers):
             if (reference_points.is_cuda and not torch.is_grad_enabled() and query.dtype in (torch.float32, torch.bfloat16)
                     and reference_points.dtype == torch.float32 and valid_ratios.dtype == torch.float32
@@ -306,7 +337,9 @@ class RelationTransformerDecoder(nn.Module):
             query = layer(query=query, query_pos=query_pos, reference_points=ref_in, value=value,
                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                           key_padding_mask=key_padding_mask, self_attn_mask=pos_relation,
-                          **({} if qpp is None else {"query_plus_pos": qpp}))
+                          **({} if qpp is None else {"query_plus_pos": qpp}),
+                          **({} if values_all is None else
+                             {"projected_value": values_all[..., idx * self.embed_dim:(idx + 1) * self.embed_dim]}))
             normed = add_norm(self.norm, query)
             out_class = self.class_head[idx](normed)
             last = idx == self.num_layers - 1

@@ -605,6 +605,41 @@ def test_fused_box_head_matches_the_unfused_sequence():
         assert (got_l - w).abs().max().item() <= 4e-3 and (got_l[0, 1] == 1.0).all()
 
 
+def test_decoder_batched_value_projection_matches_per_layer_projections():
+    """options.decoder_value_batched: the cross-attention value projections of all decoder layers as one GEMM whose column slices
+    the gathers read in place, against the reference's sequence (value_proj inside every layer, ms_deform_attn.py:316) on the
+    same network: a padded batch, bf16.  Same products, different library kernel (N = 6 * 256 instead of 256): bf16 noise."""
+    from relation_detr_amd import options
+    from relation_detr_amd.transformer import build_relation_transformer
+    torch.manual_seed(3)
+    with options.override(decoder_value_batched=True):
+        net = build_relation_transformer(num_classes=17, d_ffn=128, enc_layers=1, dec_layers=3, num_queries=60).to(DEV).to(torch.bfloat16).eval()
+    shapes = [(40, 56), (20, 28), (10, 14), (5, 7)]
+    g = torch.Generator().manual_seed(4)
+    feats = [torch.randn(2, 256, h, w, generator=g).to(torch.bfloat16).to(DEV) for h, w in shapes]
+    pos = [(torch.randn(2, 256, h, w, generator=g) * 0.5).to(torch.bfloat16).to(DEV) for h, w in shapes]
+    masks = [torch.zeros(2, h, w, dtype=torch.bool, device=DEV) for h, w in shapes]
+    for m in masks:
+        m[1, :, m.shape[2] * 3 // 4:] = True
+    from relation_detr_amd import ops
+    calls = []
+    real = ops.ms_deform_attn_forward_fused
+    with torch.no_grad():
+        ops.ms_deform_attn_forward_fused = lambda v, *a, **kw: (calls.append(v.is_contiguous()), real(v, *a, **kw))[1]
+        try:
+            batched = net(feats, masks, pos)
+            assert calls.count(False) == 3                                     # the three decoder gathers read column slices
+            options.apply(net, decoder_value_batched=False)
+            calls.clear()
+            plain = net(feats, masks, pos)
+            assert calls.count(False) == 0
+        finally:
+            ops.ms_deform_attn_forward_fused = real
+    for a, b_ in zip(batched[:2], plain[:2]):
+        assert (a.float() - b_.float()).abs().max().item() <= 6e-2
+    assert (batched[1].float() - plain[1].float()).abs().mean().item() <= 2e-3
+
+
 def test_fused_query_pos_matches_the_unfused_sequence():
     """rdetr_query_pos_k256_bf16 (csrc/qpos.hip) against the decoder's own statements (relation_transformer.py:343-347, 452-455):
     query_pos = ref_point_head(emb) [* query_scale(query)], qpp = query + query_pos -- four bf16 GEMMs with ReLU, a product and a

@@ -618,3 +618,26 @@ def test_msda_fused_strided_producer_rows(dtype, with_mask):
     # a slice whose rows are not evenly strided falls back to a copy, not to a wrong read
     odd = torch.randn(B, 37, H, L, P, 4, device=dev).to(dtype)[..., ::2]
     assert ops._producer_row_stride(odd) is None
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_msda_fused_row_strided_value(with_mask):
+    """rdetr_msda_forward_fused_strided_bf16: the value as a 256-column slice of a wider [B, S, 6*256] buffer (the decoder's six
+    cross-attention value projections as one GEMM) gives the bits of the same call on a contiguous copy, for decoder-shaped
+    queries with 4-d reference points, with and without the in-kernel padding mask."""
+    from relation_detr_amd import ops
+    shapes = [(20, 34), (10, 17), (5, 9), (3, 5)]
+    shp, start, S = pyramid(shapes)
+    g = torch.Generator().manual_seed(17)
+    B, Nq, L = 2, 70, 4
+    wide = torch.randn(B, S, 6 * 256, generator=g).to(torch.bfloat16).to(DEV)
+    off = (torch.randn(B, Nq, 8, L, 4, 2, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    lg = torch.randn(B, Nq, 8, L * 4, generator=g).to(torch.bfloat16).to(DEV)
+    ref = torch.cat([torch.rand(B, Nq, L, 2, generator=g), torch.rand(B, Nq, L, 2, generator=g) * 0.4 + 0.05], -1).to(DEV)
+    mask = (torch.rand(B, S, generator=g) < 0.2).to(DEV) if with_mask else None
+    for l in (0, 3, 5):
+        view = wide[..., 256 * l:256 * (l + 1)].view(B, S, 8, 32)
+        assert not view.is_contiguous()
+        got = ops.ms_deform_attn_forward_fused(view, shp.to(DEV), start.to(DEV), off, lg, ref, mask)
+        want = ops.ms_deform_attn_forward_fused(view.contiguous(), shp.to(DEV), start.to(DEV), off, lg, ref, mask)
+        assert torch.equal(got, want)

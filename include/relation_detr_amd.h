@@ -184,6 +184,20 @@ int rdetr_msda_backward_f32(const float *value, const int64_t *spatial_shapes, c
                             int S, int H, int D, int L, int Nq, int P, float *grad_value,
                             float *grad_sampling_loc, float *grad_attn_weight, void *stream);
 
+/* The same gradients with a DETERMINISTIC grad_value ("deterministic alternative to atomics"; the reference's
+ * backward adds with atomicAdd, ms_deform_im2col_cuda.cuh:290-392, so its bits depend on the run): one (pixel-row key, weight)
+ * record per sample corner, a stable radix sort of the records by key, and a per-row sum in sorted = original sample order.
+ * grad_sampling_loc / grad_attn_weight are fixed-order sums in both modes.  grad_value is OVERWRITTEN (every row, no
+ * zero-initialisation needed).  workspace: rdetr_msda_backward_det_workspace_bytes() bytes, 16-byte aligned (records + sort
+ * buffers + the sort's temporary storage; 20 bytes per sample corner: 0.9 GB at B = 4 of the R50 encoder shape); that function
+ * returns 0 for empty problems / unsupported shapes and -1 when the record count exceeds 2^31.  H = 8, D = 32, P = 4, L <= 8 only
+ * (RDETR_ERR_UNSUPPORTED otherwise).  About 4x the time of the atomic kernel: for reproducible training runs. */
+long long rdetr_msda_backward_det_workspace_bytes(int B, int S, int H, int D, int L, int Nq, int P);
+int rdetr_msda_backward_det_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                const float *sampling_loc, const float *attn_weight, const float *grad_out, int B, int S, int H, int D,
+                                int L, int Nq, int P, void *workspace, long long workspace_bytes, float *grad_value,
+                                float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Position-relation bias.
  * Replaces  PositionRelationEmbedding.forward  models/bricks/relation_transformer.py:520-532

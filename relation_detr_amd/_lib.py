@@ -31,6 +31,8 @@ SIGNATURES = {
     "rdetr_msda_forward_fused_strided_bf16": [_vp, _c_ll, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_value_to_head_major_bf16": [_vp, _c_ll, _vp] + [_c_int] * 4 + [_vp, _vp],
     "rdetr_msda_backward_f32": [_vp] * 6 + [_c_int] * 7 + [_vp] * 4,
+    "rdetr_msda_backward_det_workspace_bytes": [_c_int] * 7,
+    "rdetr_msda_backward_det_f32": [_vp] * 6 + [_c_int] * 7 + [_vp, _c_ll] + [_vp] * 4,
     "rdetr_relation_bias_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp],
     "rdetr_relation_bias_ws_f32": [_vp] * 4 + [_c_int] * 5 + [_c_float] * 3 + [_vp, _vp, _vp],
     "rdetr_relation_bias_backward_workspace_bytes": [_c_int] * 3,

@@ -289,8 +289,10 @@ def msda_fast_path(H: int, D: int, L: int, P: int) -> bool:
 
 def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor,
                             sampling_loc: torch.Tensor, attn_weight: torch.Tensor, grad_output: torch.Tensor,
-                            im2col_step: int = 64):
-    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (fp32), as ms_deform_attn_cuda.cu:75-145."""
+                            im2col_step: int = 64, deterministic: Optional[bool] = None):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (fp32), as ms_deform_attn_cuda.cu:75-145.
+    ``deterministic`` (not in the reference's signature; default = ``torch.are_deterministic_algorithms_enabled()``): grad_value
+    through sorted per-row sums instead of float atomics (csrc/msda_bwd.hip; H = 8, D = 32, P = 4) -- the same bits on every run."""
     _require_device(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
     grad_output = grad_output.contiguous()
     _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
@@ -302,6 +304,23 @@ def ms_deform_attn_backward(value: torch.Tensor, spatial_shapes: torch.Tensor, l
     if tuple(grad_output.shape) != (B, Nq, H * D):
         raise _lib.RdetrError("grad_output must be [B, Nq, H*D]")
     check_levels(spatial_shapes, level_start_index, S)
+    if deterministic is None:
+        deterministic = torch.are_deterministic_algorithms_enabled()
+    if deterministic:
+        lib = _lib.load()
+        nbytes = int(lib.rdetr_msda_backward_det_workspace_bytes(B, S, H, D, L, Nq, P))
+        if nbytes < 0 or (nbytes == 0 and B * S * Nq > 0):
+            raise _lib.RdetrError("deterministic ms_deform_attn_backward: H = 8, D = 32, P = 4, L <= 8 and fewer than 2^31 sample corners only")
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=value.device)
+        grad_value = torch.empty_like(value)                    # every row is written
+        grad_loc = torch.empty_like(sampling_loc)
+        grad_attn = torch.empty_like(attn_weight)
+        st = lib.rdetr_msda_backward_det_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            grad_output.data_ptr(), B, S, H, D, L, Nq, P, ws.data_ptr(), nbytes, grad_value.data_ptr(), grad_loc.data_ptr(),
+            grad_attn.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_backward_det_f32")
+        return [grad_value, grad_loc, grad_attn]
     grad_value = torch.zeros_like(value)                       # accumulated with atomics
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)

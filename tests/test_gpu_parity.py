@@ -163,6 +163,40 @@ def test_msda_autograd_vs_oracle(rd):
     np.testing.assert_allclose(np.where(ok, l.grad.cpu().numpy(), 0), np.where(ok, gl, 0), rtol=1e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize("shapes,B,Nq", [([(12, 20), (6, 10), (3, 5), (2, 3)], 2, 37), ([(40, 56), (20, 28), (10, 14), (5, 7)], 2, 3010),
+                                         ([(10, 16), (5, 8), (3, 4), (2, 2), (1, 1)], 1, 29)])
+def test_msda_backward_deterministic_mode(rd, shapes, B, Nq):
+    """rdetr_msda_backward_det_f32: grad_value through sorted per-row sums instead of float atomics.  Same
+    gradients as the C oracle (double accumulation) within the bounds of the atomic kernel, the SAME BITS on a second run, every
+    row written without zero-initialisation, and the switch follows torch.use_deterministic_algorithms."""
+    from oracle import c_oracle
+    from relation_detr_amd import ops
+    value, shp, start, loc, attn = make_msda_inputs(B, Nq, shapes, seed=Nq, spread=0.2)
+    loc[0, 0, 0, 0, 0, 0] = float("nan")                                          # contributes nothing
+    g = torch.Generator().manual_seed(Nq + 1)
+    go = torch.randn(B, Nq, 256, generator=g)
+    dev = [t.to(DEV) for t in (value, shp, start, loc, attn, go)]
+    gv, gl, ga = ops.ms_deform_attn_backward(*dev, deterministic=True)
+    gv2, gl2, ga2 = ops.ms_deform_attn_backward(*dev, deterministic=True)
+    assert torch.equal(gv, gv2) and torch.equal(gl, gl2) and torch.equal(ga, ga2)
+    av, al, aa = ops.ms_deform_attn_backward(*dev, deterministic=False)          # the atomic kernel: same sums, another order
+    assert torch.equal(gl, al) and torch.equal(ga, aa)
+    np.testing.assert_allclose(gv.cpu().numpy(), av.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    loc_ref = loc.clone()
+    loc_ref[0, 0, 0, 0, 0, 0] = -5.0                                             # the oracle: a far-outside point instead of NaN
+    rv, rl, ra = c_oracle.msda_backward(value.numpy(), shp.numpy(), start.numpy(), loc_ref.numpy(), attn.numpy(), go.numpy())
+    np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(rv).max())))
+    np.testing.assert_allclose(ga.cpu().numpy(), ra, rtol=0, atol=1e-4 * max(1.0, float(np.abs(ra).max())))
+    was = torch.are_deterministic_algorithms_enabled()
+    try:
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        v, l_, a_ = (t.clone().requires_grad_() for t in (dev[0], dev[3], dev[4]))
+        rd.MultiScaleDeformableAttnFunction.apply(v, dev[1], dev[2], l_, a_, 64).backward(dev[5])
+        assert torch.equal(v.grad, gv)
+    finally:
+        torch.use_deterministic_algorithms(was)
+
+
 def test_msda_backward_generic_shapes(rd):
     from oracle import c_oracle
     value, shp, start, loc, attn = make_msda_inputs(2, 21, [(8, 12), (4, 6)], H=4, D=16, P=2, seed=8)

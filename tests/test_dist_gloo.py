@@ -97,6 +97,27 @@ def test_bench_launcher_ends_all_ranks_when_one_dies():
     assert time.monotonic() - t0 < 90                   # not the ~10-minute collective timeout
 
 
+def test_bench_under_torch_distributed_run_two_ranks():
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- with N = 2 on the CPU (dry run, gloo): the env:// rendezvous torchrun
+    exports is used as it is, rank 0 prints ONE line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    assert lines[0]["n_gpus"] == 2 and lines[0]["world_size_seen"] == 2 and lines[0]["gather_ok"] is True
+
+
 def test_bench_refuses_world_size_mismatch():
     """--gpus N must agree with the ranks actually launched: a silent 1-GPU run labelled otherwise is refused."""
     rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],

@@ -152,8 +152,8 @@ def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SH
     """Average duration of the dominant kernel from device events recorded on the stream it is launched on.
     layout None = the one the stack runs the kernel in: head-major [B,H,S,D] for bf16 (written by the value projection's
     epilogue, relation_detr_amd/ms_deform_attn.py), the reference operator's [B,S,H,D] for fp32.
-    ``busy``: a callable that enqueues ~50 ms of the stack's own work.  It runs right before the timed launches, with no host
-    synchronisation in between, so that the kernel is timed at the clocks the stack runs it at: after an idle gap (the inputs
+    ``busy``: a callable that enqueues ~50 ms of the stack's own work.  It runs right before 2 x reps untimed and reps timed
+    launches, with no host synchronisation in between, so that the kernel is timed at sustained clocks: after an idle gap (the inputs
     are built on the host) the first ~200 launches run at ramping clocks -- 135 -> 107 us over 25 ms, 119 us after a 50-ms
     pause (tools/exp_kernel_timing.py, profiles/r03/kernel_timing_vs_clock_ramp.txt); round 2's 3 warm-up + 20 timed launches
     measured the ramp."""
@@ -169,6 +169,8 @@ def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SH
     torch.cuda.synchronize()
     if busy is not None:
         busy()
+        for _ in range(2 * reps):                           # ... and the kernel itself up to its own steady state
+            rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

@@ -75,16 +75,26 @@ VALUE_BSHD, VALUE_BHSD = 0, 1                     # include/relation_detr_amd.h:
 MSDA_AUTO, MSDA_DIRECT, MSDA_WINDOW, MSDA_AUTO_PACKED = 0, 1, 2, 3     # RDETR_MSDA_*
 
 
+_window_ok_cache: dict = {}
+
+
 def levels_window_ok(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, num_value: int) -> bool:
     """Precondition of the LDS-window kernel (include/relation_detr_amd.h, RDETR_MSDA_WINDOW): the levels tile [0, S) exactly
     -- cumulative starts, sum(h*w) == S -- and none outgrows level 0.  From the cached host copy of the table, through the
     library's own host helper (one definition of the rule)."""
     import ctypes
     shapes, starts = host_levels(spatial_shapes, level_start_index)
-    n = len(shapes)
-    hs = (ctypes.c_int64 * (2 * n))(*[v for hw in shapes for v in hw])
-    st = (ctypes.c_int64 * n)(*starts)
-    return bool(_lib.load().rdetr_msda_levels_window_ok(hs, st, n, num_value))
+    key = (shapes, starts, int(num_value))
+    hit = _window_ok_cache.get(key)                     # a few distinct pyramids per process: decided once each
+    if hit is None:
+        n = len(shapes)
+        hs = (ctypes.c_int64 * (2 * n))(*[v for hw in shapes for v in hw])
+        st = (ctypes.c_int64 * n)(*starts)
+        hit = bool(_lib.load().rdetr_msda_levels_window_ok(hs, st, n, num_value))
+        if len(_window_ok_cache) > 256:
+            _window_ok_cache.clear()
+        _window_ok_cache[key] = hit
+    return hit
 
 
 def _msda_algo(algo: str, spatial_shapes, level_start_index, num_value: int) -> int:

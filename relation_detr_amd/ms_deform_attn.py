@@ -170,9 +170,22 @@ class MultiScaleDeformableAttention(nn.Module):
         pre = (projected_value is not None and fused and not head_major and value.dtype == torch.bfloat16
                and (key_padding_mask is None or mask_in_kernel) and projected_value.dtype == torch.bfloat16
                and tuple(projected_value.shape) == tuple(value.shape))
-        v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not (mask_in_kernel or head_major),
-                                              merged=fused and self.options.merged_proj,
-                                              want_value=not (proj_hm or pre))
+        fused_in = None
+        if proj_hm and self.options.encoder_proj and self.options.merged_proj and self.num_levels == 4 and query.shape == value.shape:
+            # encoder layer, bf16: value_proj (head-major, padded rows zero) and the merged offsets | logits projection of
+            # `query` in ONE kernel (csrc/proj.hip) instead of two launches of ~20 us
+            wq, bq = self._merged_query_projection()
+            if ops.encoder_proj_supported(value, query, self.value_proj.weight, wq):
+                fused_in = ops.encoder_proj(value, query, self.value_proj.weight, self.value_proj.bias, wq, bq, key_padding_mask)
+        if fused_in is not None:
+            B_, Nq_ = query.shape[:2]
+            H_, L_, P_ = self.num_heads, self.num_levels, self.num_points
+            n_off = H_ * L_ * P_ * 2
+            v, offsets, logits = None, fused_in[1][..., :n_off].view(B_, Nq_, H_, L_, P_, 2), fused_in[1][..., n_off:].view(B_, Nq_, H_, L_ * P_)
+        else:
+            v, offsets, logits = self._projections(query, value, key_padding_mask, fill=not (mask_in_kernel or head_major),
+                                                  merged=fused and self.options.merged_proj,
+                                                  want_value=not (proj_hm or pre))
         if pre:
             v = projected_value.view(*value.shape[:2], self.num_heads, self.embed_dim // self.num_heads)
         vdt = value.dtype if proj_hm else v.dtype
@@ -180,7 +193,9 @@ class MultiScaleDeformableAttention(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (v, offsets, logits, reference_points))
         if fused and head_major and vdt == torch.bfloat16:
-            if proj_hm:
+            if fused_in is not None:
+                vh = fused_in[0]
+            elif proj_hm:
                 vh = ops.value_proj_head_major(value, self.value_proj.weight, self.value_proj.bias, key_padding_mask)
             else:
                 vh = ops.value_to_head_major(v.view(v.shape[0], v.shape[1], -1), key_padding_mask)

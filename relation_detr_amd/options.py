@@ -42,6 +42,7 @@ class Options:
     value_proj_hm: bool = True       # ... written by the value projection's own epilogue
     merged_proj: bool = True         # sampling_offsets + attention_weights as one GEMM
     proj_ln: bool = True             # output_proj + residual + LayerNorm in one kernel
+    encoder_proj: bool = True        # value_proj (head-major) + the merged query projection of an encoder layer in one kernel
 
     @classmethod
     def from_env(cls, env: Mapping[str, str] = os.environ) -> "Options":

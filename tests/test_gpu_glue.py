@@ -640,6 +640,40 @@ def test_decoder_batched_value_projection_matches_per_layer_projections():
     assert (batched[1].float() - plain[1].float()).abs().mean().item() <= 2e-3
 
 
+@pytest.mark.parametrize("B,S", [(2, 22323), (1, 4096 + 37), (3, 700)])
+def test_encoder_proj_matches_the_separate_projections(B, S):
+    """rdetr_encoder_proj_k256_bf16 (csrc/proj.hip): value_proj in the head-major layout with the padded rows zero + the merged
+    sampling_offsets | attention_weights projection of an encoder layer in one kernel, against the two launches it replaces
+    (rdetr_linear_k256_hm_bf16, pinned by its own test, and the library GEMM) and the fp32 products of the bf16 operands.
+    Inputs are column slices of a wider buffer (the encoder's memory-fusion input), row tails on every tile shape."""
+    from relation_detr_amd import ops
+    g = torch.Generator().manual_seed(S)
+    wide = torch.randn(B, S, 3 * 256, generator=g).to(torch.bfloat16).to(DEV)
+    x = wide[..., 256:512]
+    xq = (torch.randn(B, S, 256, generator=g)).to(torch.bfloat16).to(DEV)
+    wv = (torch.randn(256, 256, generator=g) * 0.06).to(torch.bfloat16).to(DEV)
+    bv = (torch.randn(256, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    wq = (torch.randn(384, 256, generator=g) * 0.06).to(torch.bfloat16).to(DEV)
+    bq = (torch.randn(384, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    mask = (torch.rand(B, S, generator=g) < 0.15).to(DEV)
+    vh, q = ops.encoder_proj(x, xq, wv, bv, wq, bq, mask)
+    assert vh.shape == (B, 8, S, 32) and q.shape == (B, S, 384)
+    want_v = (x.float() @ wv.float().t() + bv.float()).masked_fill(mask[..., None], 0.0).view(B, S, 8, 32).permute(0, 2, 1, 3)
+    want_q = xq.float() @ wq.float().t() + bq.float()
+    for got, want in ((vh, want_v), (q, want_q)):
+        err = (got.float() - want).abs()
+        assert (err <= 2.0 ** -8 * want.abs() + 2e-3).all(), err.max().item()          # one bf16 rounding of an fp32-accumulated product
+    assert (vh.float().permute(0, 2, 1, 3).reshape(B, S, 256)[mask] == 0).all()
+    old_v = ops.value_proj_head_major(x, wv, bv, mask)
+    assert (vh.float() - old_v.float()).abs().max().item() <= 2.0 ** -7 * want_v.abs().max().item()
+    lib_q = torch.nn.functional.linear(xq, wq, bq)
+    assert (q.float() - lib_q.float()).abs().max().item() <= 2.0 ** -7 * want_q.abs().max().item()
+    # no mask, no biases
+    vh2, q2 = ops.encoder_proj(x, xq, wv, None, wq, None, None)
+    assert ((vh2.float() - (x.float() @ wv.float().t()).view(B, S, 8, 32).permute(0, 2, 1, 3)).abs() <= 2.0 ** -8 * want_v.abs().max().item() + 2e-3).all()
+    assert ((q2.float() - xq.float() @ wq.float().t()).abs() <= 2.0 ** -8 * want_q.abs().max().item() + 2e-3).all()
+
+
 def test_fused_query_pos_matches_the_unfused_sequence():
     """rdetr_query_pos_k256_bf16 (csrc/qpos.hip) against the decoder's own statements (relation_transformer.py:343-347, 452-455):
     query_pos = ref_point_head(emb) [* query_scale(query)], qpp = query + query_pos -- four bf16 GEMMs with ReLU, a product and a

@@ -36,11 +36,12 @@ def timed(fn, reps=20, rounds=30):
     return e0.elapsed_time(e1) / (reps * rounds) * 1e3
 
 
-for rows in (1800, 3600):
-    emb = torch.randn(2, rows // 2, 512, device=dev).to(torch.bfloat16)
-    q = torch.randn(2, rows // 2, 256, device=dev).to(torch.bfloat16)
-    fused = timed(lambda: ops.query_pos_k256(emb, q, head.layers, scale.layers))
-    fused0 = timed(lambda: ops.query_pos_k256(emb, q, head.layers, None))
-    unfused = timed(lambda: ops.scaled_pos(head(emb), scale(q), q))
-    unfused0 = timed(lambda: head(emb))
-    print(f"rows {rows}: fused {fused:.1f} us (layer 0: {fused0:.1f}) | unfused 4 GEMMs + scaled_pos {unfused:.1f} us (layer 0, 2 GEMMs: {unfused0:.1f})")
+if __name__ == "__main__":
+  for rows in (1800, 3600):
+      emb = torch.randn(2, rows // 2, 512, device=dev).to(torch.bfloat16)
+      q = torch.randn(2, rows // 2, 256, device=dev).to(torch.bfloat16)
+      fused = timed(lambda: ops.query_pos_k256(emb, q, head.layers, scale.layers))
+      fused0 = timed(lambda: ops.query_pos_k256(emb, q, head.layers, None))
+      unfused = timed(lambda: ops.scaled_pos(head(emb), scale(q), q))
+      unfused0 = timed(lambda: head(emb))
+      print(f"rows {rows}: fused {fused:.1f} us (layer 0: {fused0:.1f}) | unfused 4 GEMMs + scaled_pos {unfused:.1f} us (layer 0, 2 GEMMs: {unfused0:.1f})")

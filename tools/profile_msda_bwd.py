@@ -23,3 +23,18 @@ t = e0.elapsed_time(e1) / 5 * 1e-3
 atomic_bytes = B * S * 8 * L * 4 * 4 * 32 * 4
 print(f"backward encoder shape B={B}: {t*1e3:.2f} ms (includes the grad_value zero-fill), atomic bytes {atomic_bytes/1e9:.2f} GB "
       f"-> {atomic_bytes/t/1e12:.2f} TB/s of float atomics (chip-wide rate ~1.3 TB/s)")
+
+# deterministic mode (records + stable radix sort + per-row sums, csrc/msda_bwd.hip)
+from relation_detr_amd import ops
+for _ in range(2):
+    det = ops.ms_deform_attn_backward(value, shapes, start, loc, attn, go, 64, deterministic=True)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    det = ops.ms_deform_attn_backward(value, shapes, start, loc, attn, go, 64, deterministic=True)
+e1.record(); torch.cuda.synchronize()
+td = e0.elapsed_time(e1) / 5 * 1e-3
+atom = rd.ms_deform_attn_backward(value, shapes, start, loc, attn, go, 64)
+det2 = ops.ms_deform_attn_backward(value, shapes, start, loc, attn, go, 64, deterministic=True)
+print(f"deterministic mode B={B}: {td*1e3:.2f} ms ({td/t:.1f}x the atomic kernel); rerun bit-identical: {torch.equal(det[0], det2[0])}; "
+      f"max |det - atomic| {float((det[0] - atom[0]).abs().max()):.2e} at max |grad_value| {float(atom[0].abs().max()):.2e}")

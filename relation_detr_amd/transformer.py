@@ -277,9 +277,10 @@ class RelationTransformerDecoder(nn.Module):
         column slice in place (csrc/msda_fwd.hip takes the pixel stride).  The reference runs the six projections one per layer
         on the same encoder memory (relation_transformer.py:464-471 -> ms_deform_attn.py:316); batched they are one chip-filling
         launch ahead of the decoder's chain of small launches instead of six launches on it.  OPT-IN (options.decoder_value_batched):
-        measured 1 % SLOWER in the two-group replay (978 vs 988 images/s, same box) -- on one stream the one GEMM is as long as
-        the six it replaces, and a 100-us chip-filling launch holds up the other image group where six 22-us ones interleave
-        with its small launches; it pays only where the projections can run BESIDE the chain.  The weights stay owned by the
+        measured 1 % SLOWER in the two-group replay (978 vs 988 images/s, same box) -- the batched GEMM stays on the decoder's
+        own stream, so it saves at most the start-up of five launches, and one long chip-filling launch in front of the chain
+        is worse for the other image group than six short ones along it; it would pay where the projections can run BESIDE
+        the chain.  The weights stay owned by the
         layers' nn.Linear modules (state_dict keys unchanged); the concatenation is cached until one of them changes."""
         projs = [layer.cross_attn.value_proj for layer in self.layers]
         key = tuple((p.weight._version, p.bias._version, p.weight.data_ptr(), p.weight.dtype) for p in projs)

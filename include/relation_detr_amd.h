@@ -390,15 +390,17 @@ int rdetr_query_pos_k256_bf16(const uint16_t *emb, long long lde, const uint16_t
 /* The three input projections of an ENCODER layer's MultiScaleDeformableAttention in one launch
  * (models/bricks/ms_deform_attn.py:315-327; called from relation_transformer.py:262-269 with value = query, query = query + pos):
  *     out_hm [B, 8, S, 32] = head-major(value_proj(x)), rows of padded positions zero        (:315-321)
- *     out_q  [B*S, 384]    = [sampling_offsets ; attention_weights](xq), raw outputs          (:322-327; the fused gather reads the
+ *     out_q  [B*S, q_cols] = [sampling_offsets ; attention_weights](xq), raw outputs          (:322-327; the fused gather reads the
  *                                                                                              two column slices in place)
+ * q_cols = 3 * heads * levels * points = 384 (4 feature levels) or 480 (5: the FocalNet configuration); anything else is
+ * RDETR_ERR_UNSUPPORTED.
  * x, xq [B*S, 256] bf16 (row strides ldx / ldq elements, multiples of 8, 16-byte aligned bases); pwv = value_proj.weight packed by
- * rdetr_linear_pack_k256_bf16; pwq = [sampling_offsets.weight ; attention_weights.weight ; 128 zero rows] = [512, 256] as two packed
- * [256, 256] blocks, one after the other; bv [256] / bq [384] bf16 or NULL; row_mask = key_padding_mask u8 [B*S] or NULL.
- * Replaces rdetr_linear_k256_hm_bf16 + one N = 384 GEMM: same products, fp32 accumulation, outputs rounded to bf16 once. */
+ * rdetr_linear_pack_k256_bf16; pwq = [sampling_offsets.weight ; attention_weights.weight ; zero rows] = [512, 256] as two packed
+ * [256, 256] blocks, one after the other; bv [256] / bq [q_cols] bf16 or NULL; row_mask = key_padding_mask u8 [B*S] or NULL.
+ * Replaces rdetr_linear_k256_hm_bf16 + one N = q_cols GEMM: same products, fp32 accumulation, outputs rounded to bf16 once. */
 int rdetr_encoder_proj_k256_bf16(const uint16_t *x, long long ldx, const uint16_t *xq, long long ldq, const uint16_t *pwv,
                                  const uint16_t *bv, const uint16_t *pwq, const uint16_t *bq, const uint8_t *row_mask, int B, int S,
-                                 uint16_t *out_hm, uint16_t *out_q, void *stream);
+                                 int q_cols, uint16_t *out_hm, uint16_t *out_q, void *stream);
 
 /* PostProcess after its top-k (models/bricks/post_process.py:30-44) in one launch: for rank r of image b
  *   out[b][r] = (x1, y1, x2, y2, score, label) with box = boxes[b][index / C] (cxcywh in [0, 1]) converted to xyxy and scaled by the

@@ -48,7 +48,7 @@ SIGNATURES = {
     "rdetr_topk": [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "rdetr_box_head_k256_bf16": [_vp, _c_ll, _vp, _c_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_float, _c_ll, _vp, _vp, _vp],
     "rdetr_query_pos_k256_bf16": [_vp, _c_ll, _vp, _c_ll] + [_vp] * 9 + [_c_ll, _vp, _vp, _vp],
-    "rdetr_encoder_proj_k256_bf16": [_vp, _c_ll, _vp, _c_ll] + [_vp] * 5 + [_c_int, _c_int, _vp, _vp, _vp],
+    "rdetr_encoder_proj_k256_bf16": [_vp, _c_ll, _vp, _c_ll] + [_vp] * 5 + [_c_int, _c_int, _c_int, _vp, _vp, _vp],
     "rdetr_detections_from_topk": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "rdetr_scaled_pos": [_vp, _vp, _vp, _c_ll, _c_int, _vp, _vp, _vp],
     "rdetr_decoder_reference": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _vp, _vp, _c_int, _vp],

@@ -156,6 +156,42 @@ template <> struct LoadQ<uint16_t, 8> {
     }
 };
 
+// 5 points per lane (5 levels x 4 points over the 4 lanes of a bf16 head row): runs of 5 / 10 values that start at a multiple
+// of their own size only -- the alignment is stated and the compiler chooses the widest legal loads (dwordx4 + dword, ...)
+template <> struct LoadQ<uint16_t, 10> {
+    static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[10])
+    {
+        unsigned r[5];
+        __builtin_memcpy(r, __builtin_assume_aligned(p, 4), 20);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+        }
+    }
+};
+template <> struct LoadQ<uint16_t, 5> {
+    static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[5])
+    {
+        uint16_t r[5];
+        __builtin_memcpy(r, __builtin_assume_aligned(p, 2), 10);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = bf16_bits_to_f32(r[i]);
+    }
+};
+template <> struct LoadQ<float, 10> {
+    static __device__ __forceinline__ void run(const float *p, float (&v)[10])
+    {
+        __builtin_memcpy(v, __builtin_assume_aligned(p, 8), 40);
+    }
+};
+template <> struct LoadQ<float, 5> {
+    static __device__ __forceinline__ void run(const float *p, float (&v)[5])
+    {
+        __builtin_memcpy(v, __builtin_assume_aligned(p, 4), 20);
+    }
+};
+
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -210,7 +246,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     // LT == 4: a lane prepares kPtsPerLane CONSECUTIVE points (4 = one level for bf16, 2 for fp32), so that its share of the
     // locations / weights (or raw offsets / logits / reference point) arrives with 3 vector loads instead of 8-12 narrow ones
     // -- the texture addresser's instruction rate is one of the kernel's three co-limiters.  Otherwise points sub, sub + kSub, ...
-    constexpr bool kConsec = LT == 4;
+    // LT == 5, bf16: 5 consecutive points per lane -- lane `sub` holds the last 4 - sub points of level sub and the first sub + 1
+    // of level sub + 1 (kSpan: two sets of level constants / reference points per lane), 5 vector loads instead of 15.
+    constexpr bool kSpan = LT == 5 && kSub == 4;
+    constexpr bool kConsec = LT == 4 || kSpan;
     constexpr bool kMM = sizeof(T) == 2;         // bf16: the weighted sum on the matrix cores (mfma_point)
     constexpr bool kFast = FUSED && sizeof(T) == 2;      // bf16 producer inputs: see the softmax below
     const int L = LT ? LT : L_rt;
@@ -233,20 +272,27 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     // kConsec: no table in LDS and no barrier -- a wave starts on its inputs at once.  The 4 levels' constants come by scalar
     // loads (uniform addresses) and a lane selects those of ITS level; a memory round trip + barrier in front of every
     // workgroup's input loads was a third of the launch.
-    int my_h = 0, my_w = 0, my_start = 0;
+    int my_h = 0, my_w = 0, my_start = 0, my_h1 = 0, my_w1 = 0, my_start1 = 0;       // ..1: the lane's second level (kSpan)
     if constexpr (kConsec) {
         const int my_level = ((int)(threadIdx.x % kSub) * kPtsPerLane) / kPoints;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
+        for (int l = 0; l < LT; ++l) {
             const int h = (int)shapes[2 * l], w = (int)shapes[2 * l + 1], st = (int)level_start[l];
             my_h = my_level == l ? h : my_h;
             my_w = my_level == l ? w : my_w;
             my_start = my_level == l ? st : my_start;
+            if constexpr (kSpan) {
+                my_h1 = my_level + 1 == l ? h : my_h1;
+                my_w1 = my_level + 1 == l ? w : my_w1;
+                my_start1 = my_level + 1 == l ? st : my_start1;
+            }
         }
     }
-    auto level_h = [&](int l) { return kConsec ? my_h : lvl.h[l]; };
-    auto level_w = [&](int l) { return kConsec ? my_w : lvl.w[l]; };
-    auto level_start_of = [&](int l) { return kConsec ? my_start : lvl.start[l]; };
+    // k = index of the point among the lane's own (kSpan: its points k >= 4 - sub belong to the lane's second level)
+    auto second_level = [&](int k) { return kSpan && k >= kPoints - (int)(threadIdx.x % kSub); };
+    auto level_h = [&](int l, int k) { return kConsec ? (second_level(k) ? my_h1 : my_h) : lvl.h[l]; };
+    auto level_w = [&](int l, int k) { return kConsec ? (second_level(k) ? my_w1 : my_w) : lvl.w[l]; };
+    auto level_start_of = [&](int l, int k) { return kConsec ? (second_level(k) ? my_start1 : my_start) : lvl.start[l]; };
 
     // logical block -> (image b, head m, tile of consecutive queries); tiles of one (b, m) are consecutive
     const int logical = xcd_contiguous_block(blockIdx.x, nblk);
@@ -317,15 +363,25 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
         }
         sum = group_sum<kSub>(sum);
         const float inv_sum = 1.0f / sum;
-        f32x4 rc = {0.f, 0.f, 0.f, 0.f};          // kConsec: the lane's points share a level -> one reference point
-        const float inv_w = kConsec ? 1.0f / (float)level_w(0) : 0.f, inv_h = kConsec ? 1.0f / (float)level_h(0) : 0.f;
+        // kConsec: the lane's points share a level -> one reference point (kSpan: two levels -> two, rc1 for the second)
+        f32x4 rc = {0.f, 0.f, 0.f, 0.f}, rc0 = {0.f, 0.f, 0.f, 0.f}, rc1 = {0.f, 0.f, 0.f, 0.f};
+        const float inv_w0 = kConsec ? 1.0f / (float)my_w : 0.f, inv_h0 = kConsec ? 1.0f / (float)my_h : 0.f;
+        const float inv_w1 = kSpan ? 1.0f / (float)my_w1 : 0.f, inv_h1 = kSpan ? 1.0f / (float)my_h1 : 0.f;
         if constexpr (kConsec) {
             const float *rp = ref + (row * L + point_of(0) / kPoints) * (size_t)ref_dim;
             if (ref_dim == 2) {
-                const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
-                rc = f32x4{r2.x, r2.y, 0.f, 0.f};
+                if constexpr (kSpan) {                 // levels sub, sub + 1: four floats, 8-byte aligned
+                    float r4[4];
+                    __builtin_memcpy(r4, __builtin_assume_aligned(rp, 8), 16);
+                    rc0 = f32x4{r4[0], r4[1], 0.f, 0.f};
+                    rc1 = f32x4{r4[2], r4[3], 0.f, 0.f};
+                } else {
+                    const f32x2 r2 = *reinterpret_cast<const f32x2 *>(rp);
+                    rc0 = f32x4{r2.x, r2.y, 0.f, 0.f};
+                }
             } else {
-                rc = *reinterpret_cast<const f32x4 *>(rp);
+                rc0 = *reinterpret_cast<const f32x4 *>(rp);
+                if constexpr (kSpan) rc1 = *reinterpret_cast<const f32x4 *>(rp + 4);
             }
         }
 #pragma unroll
@@ -335,15 +391,17 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             if constexpr (!kConsec) {
                 const float *rp = ref + (row * L + l) * (size_t)ref_dim;
                 rc = ref_dim == 2 ? f32x4{rp[0], rp[1], 0.f, 0.f} : f32x4{rp[0], rp[1], rp[2], rp[3]};
+            } else {
+                rc = second_level(k) ? rc1 : rc0;
             }
             pa[k] = kFast ? pa[k] * inv_sum : pa[k] / sum;
             if (ref_dim == 2) {
                 if (kFast && kConsec) {
-                    pxy[k].x = rc.x + pxy[k].x * inv_w;
-                    pxy[k].y = rc.y + pxy[k].y * inv_h;
+                    pxy[k].x = rc.x + pxy[k].x * (second_level(k) ? inv_w1 : inv_w0);
+                    pxy[k].y = rc.y + pxy[k].y * (second_level(k) ? inv_h1 : inv_h0);
                 } else {
-                    pxy[k].x = rc.x + pxy[k].x / (float)level_w(l);
-                    pxy[k].y = rc.y + pxy[k].y / (float)level_h(l);
+                    pxy[k].x = rc.x + pxy[k].x / (float)level_w(l, k);
+                    pxy[k].y = rc.y + pxy[k].y / (float)level_h(l, k);
                 }
             } else {
                 pxy[k].x = rc.x + pxy[k].x * (1.0f / kPoints) * rc.z * 0.5f;
@@ -376,7 +434,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             const f32x2 xy = pxy[k];
             const float a = pa[k];
             const int l = pt / kPoints;
-            const int h = level_h(l), w = level_w(l);
+            const int h = level_h(l, k), w = level_w(l, k);
             const float x = xy.x * (float)w - 0.5f;
             const float y = xy.y * (float)h - 0.5f;
             const bool inside = qok && (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);   // false for NaN
@@ -385,7 +443,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
             const bool okx0 = inside && x0 >= 0, okx1 = inside && x0 + 1 <= w - 1;
             const bool oky0 = y0 >= 0, oky1 = y0 + 1 <= h - 1;
-            const unsigned base = (unsigned)(level_start_of(l) + y0 * w + x0) * pixb;
+            const unsigned base = (unsigned)(level_start_of(l, k) + y0 * w + x0) * pixb;
             const unsigned rowb = (unsigned)w * pixb;
             u32x4 o;
             o.x = (okx0 && oky0) ? base : kInvalidOffset;
@@ -393,7 +451,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             o.z = (okx0 && oky1) ? base + rowb : kInvalidOffset;
             o.w = (okx1 && oky1) ? base + rowb + pixb : kInvalidOffset;
             if (pad_mask) {                  // key_padding_mask: a padded pixel's projected value row counts as zero
-                const unsigned char *mp = pad_mask + (size_t)b * S + (level_start_of(l) + y0 * w + x0);     // (ms_deform_attn.py:316-319)
+                const unsigned char *mp = pad_mask + (size_t)b * S + (level_start_of(l, k) + y0 * w + x0);     // (ms_deform_attn.py:316-319)
                 if (okx0 && oky0 && mp[0]) o.x = kInvalidOffset;
                 if (okx1 && oky0 && mp[1]) o.y = kInvalidOffset;
                 if (okx0 && oky1 && mp[w]) o.z = kInvalidOffset;
@@ -539,10 +597,14 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
     const bool vec_ok = reinterpret_cast<uintptr_t>(src_a) % 16 == 0 && reinterpret_cast<uintptr_t>(src_b) % 16 == 0 &&
                         (!FUSED || (reinterpret_cast<uintptr_t>(ref) % 16 == 0 && (ld_a * (int)sizeof(T)) % 16 == 0 &&
                                     (ld_b * (int)sizeof(T)) % 16 == 0));
+    // the 5-level bf16 kernel reads runs of 5 / 10 values at their natural alignment and two reference points at once
+    const bool vec5_ok = sizeof(T) == 4 ||
+                         (reinterpret_cast<uintptr_t>(src_a) % 8 == 0 && reinterpret_cast<uintptr_t>(src_b) % 4 == 0 &&
+                          (!FUSED || (reinterpret_cast<uintptr_t>(ref) % 16 == 0 && (ld_a * (int)sizeof(T)) % 4 == 0)));
     if (L == 4 && vec_ok)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
                            src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
-    else if (L == 5)
+    else if (L == 5 && vec5_ok)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
                            src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
     else

@@ -171,7 +171,7 @@ class MultiScaleDeformableAttention(nn.Module):
                and (key_padding_mask is None or mask_in_kernel) and projected_value.dtype == torch.bfloat16
                and tuple(projected_value.shape) == tuple(value.shape))
         fused_in = None
-        if proj_hm and self.options.encoder_proj and self.options.merged_proj and self.num_levels == 4 and query.shape == value.shape:
+        if proj_hm and self.options.encoder_proj and self.options.merged_proj and self.num_levels in (4, 5) and query.shape == value.shape:
             # encoder layer, bf16: value_proj (head-major, padded rows zero) and the merged offsets | logits projection of
             # `query` in ONE kernel (csrc/proj.hip) instead of two launches of ~20 us
             wq, bq = self._merged_query_projection()

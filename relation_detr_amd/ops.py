@@ -776,7 +776,7 @@ def query_pos_k256(emb: torch.Tensor, query: torch.Tensor, head_layers, scale_la
 def encoder_proj_supported(x: torch.Tensor, xq: torch.Tensor, wv: torch.Tensor, wq: torch.Tensor) -> bool:
     if not (x.is_cuda and x.dim() == 3 and xq.shape == x.shape and x.dtype == torch.bfloat16 and xq.dtype == torch.bfloat16
             and x.shape[-1] == 256 and wv.dtype == torch.bfloat16 and wq.dtype == torch.bfloat16 and tuple(wv.shape) == (256, 256)
-            and tuple(wq.shape) == (384, 256) and wv.is_contiguous() and wq.is_contiguous() and wv.data_ptr() % 16 == 0):
+            and tuple(wq.shape) in ((384, 256), (480, 256)) and wv.is_contiguous() and wq.is_contiguous() and wv.data_ptr() % 16 == 0):
         return False
     try:
         for t in (x, xq):
@@ -789,10 +789,10 @@ def encoder_proj_supported(x: torch.Tensor, xq: torch.Tensor, wv: torch.Tensor, 
 
 
 def _packed_query_proj(wq: torch.Tensor) -> torch.Tensor:
-    """[384, 256] merged query-projection weight -> two packed [256, 256] blocks (the last 128 rows zero); cached."""
+    """[384 | 480, 256] merged query-projection weight -> two packed [256, 256] blocks (zero rows up to 512); cached."""
     def build():
         full = torch.zeros(512, 256, dtype=torch.bfloat16, device=wq.device)
-        full[:384].copy_(wq.detach())
+        full[:wq.shape[0]].copy_(wq.detach())
         packed = torch.empty(2 * 256 * 256, dtype=torch.bfloat16, device=wq.device)
         for blk in range(2):
             st = _lib.load().rdetr_linear_pack_k256_bf16(full[256 * blk:256 * (blk + 1)].data_ptr(), packed.data_ptr() + blk * 256 * 256 * 2,
@@ -807,17 +807,19 @@ def _packed_query_proj(wq: torch.Tensor) -> torch.Tensor:
 def encoder_proj(x: torch.Tensor, xq: torch.Tensor, wv: torch.Tensor, bv: Optional[torch.Tensor], wq: torch.Tensor,
                  bq: Optional[torch.Tensor], key_padding_mask: Optional[torch.Tensor] = None):
     """The three input projections of an encoder layer's MSDA in one kernel (csrc/proj.hip): x, xq [B, S, 256] bf16 (rows may be
-    column slices); wv [256, 256] = value_proj.weight, wq [384, 256] = [sampling_offsets.weight ; attention_weights.weight] ->
-    (value head-major [B, 8, S, 32] with padded rows zero, raw [B, S, 384] offsets | logits).  Inference only."""
+    column slices); wv [256, 256] = value_proj.weight, wq [384 | 480, 256] = [sampling_offsets.weight ; attention_weights.weight]
+    (4 | 5 feature levels) -> (value head-major [B, 8, S, 32] with padded rows zero, raw [B, S, 384 | 480] offsets | logits).
+    Inference only."""
     _require_device(x, xq, wv, bv, wq, bq, key_padding_mask)
     if not encoder_proj_supported(x, xq, wv, wq):
-        raise _lib.RdetrError("encoder_proj: bf16 [B, S, 256] inputs with 16-byte aligned rows, wv [256, 256], wq [384, 256]")
+        raise _lib.RdetrError("encoder_proj: bf16 [B, S, 256] inputs with 16-byte aligned rows, wv [256, 256], wq [384 | 480, 256]")
     B, S, _ = x.shape
+    q_cols = wq.shape[0]
     _, _, ldx = _rows_view(x, "encoder_proj")
     _, _, ldq = _rows_view(xq, "encoder_proj")
-    for t, n in ((bv, 256), (bq, 384)):
+    for t, n in ((bv, 256), (bq, q_cols)):
         if t is not None and (t.dtype != torch.bfloat16 or t.numel() != n):
-            raise _lib.RdetrError("encoder_proj: biases must be bf16 [256] / [384]")
+            raise _lib.RdetrError("encoder_proj: biases must be bf16 [256] / [384 | 480]")
     mask_ptr = None
     if key_padding_mask is not None:
         if tuple(key_padding_mask.shape) != (B, S):
@@ -826,10 +828,10 @@ def encoder_proj(x: torch.Tensor, xq: torch.Tensor, wv: torch.Tensor, bv: Option
             else key_padding_mask.to(torch.uint8).contiguous()
         mask_ptr = mask_u8.data_ptr()
     out_hm = torch.empty(B, 8, S, 32, dtype=torch.bfloat16, device=x.device)
-    out_q = torch.empty(B, S, 384, dtype=torch.bfloat16, device=x.device)
+    out_q = torch.empty(B, S, q_cols, dtype=torch.bfloat16, device=x.device)
     st = _lib.load().rdetr_encoder_proj_k256_bf16(
         x.data_ptr(), ldx, xq.data_ptr(), ldq, _packed_k256(wv).data_ptr(), None if bv is None else bv.contiguous().data_ptr(),
-        _packed_query_proj(wq).data_ptr(), None if bq is None else bq.contiguous().data_ptr(), mask_ptr, B, S, out_hm.data_ptr(),
+        _packed_query_proj(wq).data_ptr(), None if bq is None else bq.contiguous().data_ptr(), mask_ptr, B, S, q_cols, out_hm.data_ptr(),
         out_q.data_ptr(), _stream_ptr(x))
     _lib.check(st, "rdetr_encoder_proj_k256_bf16")
     return out_hm, out_q

@@ -640,12 +640,13 @@ def test_decoder_batched_value_projection_matches_per_layer_projections():
     assert (batched[1].float() - plain[1].float()).abs().mean().item() <= 2e-3
 
 
-@pytest.mark.parametrize("B,S", [(2, 22323), (1, 4096 + 37), (3, 700)])
-def test_encoder_proj_matches_the_separate_projections(B, S):
+@pytest.mark.parametrize("B,S,QC", [(2, 22323, 384), (1, 4096 + 37, 384), (3, 700, 384), (1, 30011, 480), (2, 700, 480)])
+def test_encoder_proj_matches_the_separate_projections(B, S, QC):
     """rdetr_encoder_proj_k256_bf16 (csrc/proj.hip): value_proj in the head-major layout with the padded rows zero + the merged
     sampling_offsets | attention_weights projection of an encoder layer in one kernel, against the two launches it replaces
     (rdetr_linear_k256_hm_bf16, pinned by its own test, and the library GEMM) and the fp32 products of the bf16 operands.
-    Inputs are column slices of a wider buffer (the encoder's memory-fusion input), row tails on every tile shape."""
+    Inputs are column slices of a wider buffer (the encoder's memory-fusion input), row tails on every tile shape.  QC = columns of
+    the merged projection: 384 with 4 feature levels, 480 with 5 (the FocalNet configuration)."""
     from relation_detr_amd import ops
     g = torch.Generator().manual_seed(S)
     wide = torch.randn(B, S, 3 * 256, generator=g).to(torch.bfloat16).to(DEV)
@@ -653,11 +654,11 @@ def test_encoder_proj_matches_the_separate_projections(B, S):
     xq = (torch.randn(B, S, 256, generator=g)).to(torch.bfloat16).to(DEV)
     wv = (torch.randn(256, 256, generator=g) * 0.06).to(torch.bfloat16).to(DEV)
     bv = (torch.randn(256, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
-    wq = (torch.randn(384, 256, generator=g) * 0.06).to(torch.bfloat16).to(DEV)
-    bq = (torch.randn(384, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    wq = (torch.randn(QC, 256, generator=g) * 0.06).to(torch.bfloat16).to(DEV)
+    bq = (torch.randn(QC, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
     mask = (torch.rand(B, S, generator=g) < 0.15).to(DEV)
     vh, q = ops.encoder_proj(x, xq, wv, bv, wq, bq, mask)
-    assert vh.shape == (B, 8, S, 32) and q.shape == (B, S, 384)
+    assert vh.shape == (B, 8, S, 32) and q.shape == (B, S, QC)
     want_v = (x.float() @ wv.float().t() + bv.float()).masked_fill(mask[..., None], 0.0).view(B, S, 8, 32).permute(0, 2, 1, 3)
     want_q = xq.float() @ wq.float().t() + bq.float()
     for got, want in ((vh, want_v), (q, want_q)):

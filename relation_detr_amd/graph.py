@@ -83,8 +83,8 @@ class GraphedCall:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.RdetrError("GraphedCall cannot be built inside another capture")
         if not GraphedCall._build_lock.acquire(blocking=False):
-            raise _lib.RdetrError("another GraphedCall is being built (or replayed) on another thread: build graphs one at a "
-                                  "time with the device idle")
+            raise _lib.RdetrError("another GraphedCall is being built on another thread: build graphs one at a time, with the "
+                                  "device idle")
         try:
             torch.cuda.synchronize()                    # nothing of this process in flight: earlier graphs' replays have drained
             side = torch.cuda.Stream(device=self._inputs[0].device)

@@ -9,12 +9,27 @@ No CPU path: a tensor that is not on a ROCm device raises, and so does a missing
 """
 from __future__ import annotations
 
+import collections
 import weakref
 from typing import Optional, Tuple
 
 import torch
 
 from . import _lib
+
+
+_KEEP: "collections.deque" = collections.deque(maxlen=64)
+
+
+def _cptr(t: torch.Tensor) -> int:
+    """Device pointer of ``t`` made contiguous.  A copy made here must outlive the Python expression that asked for it -- the
+    launch that reads it is enqueued only after ALL arguments are evaluated, and a later argument may allocate -- so the last
+    few copies are kept referenced (small vectors: biases, LayerNorm parameters; contiguous tensors are passed through)."""
+    if t.is_contiguous():
+        return t.data_ptr()
+    c = t.contiguous()
+    _KEEP.append(c)
+    return c.data_ptr()
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -710,8 +725,8 @@ def box_head_k256(xa: torch.Tensor, xb: Optional[torch.Tensor], layers, referenc
     out_a = torch.empty_like(ref)
     out_b = torch.empty_like(ref) if xb is not None else None
     st = _lib.load().rdetr_box_head_k256_bf16(
-        xa.data_ptr(), lda, None if xb is None else xb.data_ptr(), ldb, pw1.data_ptr(), layers[0].bias.contiguous().data_ptr(),
-        pw2.data_ptr(), layers[1].bias.contiguous().data_ptr(), layers[2].weight.data_ptr(), layers[2].bias.contiguous().data_ptr(),
+        xa.data_ptr(), lda, None if xb is None else xb.data_ptr(), ldb, pw1.data_ptr(), _cptr(layers[0].bias),
+        pw2.data_ptr(), _cptr(layers[1].bias), layers[2].weight.data_ptr(), _cptr(layers[2].bias),
         ref.data_ptr(), int(reference_is_logit), float(eps), rows, out_a.data_ptr(), None if out_b is None else out_b.data_ptr(),
         _stream_ptr(xa))
     _lib.check(st, "rdetr_box_head_k256_bf16")
@@ -761,13 +776,13 @@ def query_pos_k256(emb: torch.Tensor, query: torch.Tensor, head_layers, scale_la
     p2 = _packed_k256(head_layers[1].weight)
     sc = [None] * 4
     if scale_layers is not None:
-        sc = [_packed_k256(scale_layers[0].weight).data_ptr(), scale_layers[0].bias.contiguous().data_ptr(),
-              _packed_k256(scale_layers[1].weight).data_ptr(), scale_layers[1].bias.contiguous().data_ptr()]
+        sc = [_packed_k256(scale_layers[0].weight).data_ptr(), _cptr(scale_layers[0].bias),
+              _packed_k256(scale_layers[1].weight).data_ptr(), _cptr(scale_layers[1].bias)]
     pos = torch.empty(*query.shape, dtype=torch.bfloat16, device=query.device)
     qpp = torch.empty_like(pos)
     st = _lib.load().rdetr_query_pos_k256_bf16(emb.data_ptr(), lde, query.data_ptr(), ldq, p1a.data_ptr(), p1b.data_ptr(),
-                                               head_layers[0].bias.contiguous().data_ptr(), p2.data_ptr(),
-                                               head_layers[1].bias.contiguous().data_ptr(), sc[0], sc[1], sc[2], sc[3], rows,
+                                               _cptr(head_layers[0].bias), p2.data_ptr(),
+                                               _cptr(head_layers[1].bias), sc[0], sc[1], sc[2], sc[3], rows,
                                                pos.data_ptr(), qpp.data_ptr(), _stream_ptr(query))
     _lib.check(st, "rdetr_query_pos_k256_bf16")
     return pos, qpp
@@ -830,8 +845,8 @@ def encoder_proj(x: torch.Tensor, xq: torch.Tensor, wv: torch.Tensor, bv: Option
     out_hm = torch.empty(B, 8, S, 32, dtype=torch.bfloat16, device=x.device)
     out_q = torch.empty(B, S, q_cols, dtype=torch.bfloat16, device=x.device)
     st = _lib.load().rdetr_encoder_proj_k256_bf16(
-        x.data_ptr(), ldx, xq.data_ptr(), ldq, _packed_k256(wv).data_ptr(), None if bv is None else bv.contiguous().data_ptr(),
-        _packed_query_proj(wq).data_ptr(), None if bq is None else bq.contiguous().data_ptr(), mask_ptr, B, S, q_cols, out_hm.data_ptr(),
+        x.data_ptr(), ldx, xq.data_ptr(), ldq, _packed_k256(wv).data_ptr(), None if bv is None else _cptr(bv),
+        _packed_query_proj(wq).data_ptr(), None if bq is None else _cptr(bq), mask_ptr, B, S, q_cols, out_hm.data_ptr(),
         out_q.data_ptr(), _stream_ptr(x))
     _lib.check(st, "rdetr_encoder_proj_k256_bf16")
     return out_hm, out_q
@@ -1003,7 +1018,7 @@ def linear_k256(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     orows, _, ldo = _rows_view(out, "linear_k256")
     if orows != rows or ldo % 8 or out.data_ptr() % 16:
         raise _lib.RdetrError("linear_k256: out rows must be 16-byte aligned")
-    st = _lib.load().rdetr_linear_k256_bf16(x.data_ptr(), ldx, weight.data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
+    st = _lib.load().rdetr_linear_k256_bf16(x.data_ptr(), ldx, weight.data_ptr(), None if bias is None else _cptr(bias),
                                             rows, N, int(relu), out.data_ptr(), ldo, _stream_ptr(x))
     _lib.check(st, "rdetr_linear_k256_bf16")
     return out
@@ -1029,7 +1044,7 @@ def value_proj_head_major(x: torch.Tensor, weight: torch.Tensor, bias: Optional[
             else key_padding_mask.to(torch.uint8).contiguous()
         mask_ptr = mask_u8.data_ptr()
     out = torch.empty(B, 8, S, 32, dtype=torch.bfloat16, device=x.device)
-    st = _lib.load().rdetr_linear_k256_hm_bf16(x.data_ptr(), ldx, weight.data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
+    st = _lib.load().rdetr_linear_k256_hm_bf16(x.data_ptr(), ldx, weight.data_ptr(), None if bias is None else _cptr(bias),
                                                mask_ptr, B, S, out.data_ptr(), _stream_ptr(x))
     _lib.check(st, "rdetr_linear_k256_hm_bf16")
     return out
@@ -1108,8 +1123,8 @@ def ffn_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tens
     if orows != rows or ldo % 8 or out.data_ptr() % 16:
         raise _lib.RdetrError("ffn_k256: out rows must be 16-byte aligned")
     packed = ffn_k256_packed_weights(w1, w2)
-    st = _lib.load().rdetr_ffn_k256_bf16(x.data_ptr(), ldx, packed.data_ptr(), b1.contiguous().data_ptr(),
-                                         b2.contiguous().data_ptr(), rows, F, out.data_ptr(), ldo, _stream_ptr(x))
+    st = _lib.load().rdetr_ffn_k256_bf16(x.data_ptr(), ldx, packed.data_ptr(), _cptr(b1),
+                                         _cptr(b2), rows, F, out.data_ptr(), ldo, _stream_ptr(x))
     _lib.check(st, "rdetr_ffn_k256_bf16")
     return out
 
@@ -1142,8 +1157,8 @@ def ffn_ln_k256(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.T
             raise _lib.RdetrError("ffn_ln_k256: pos rows must be 16-byte aligned")
         out2 = torch.empty(*x.shape[:-1], 256, dtype=x.dtype, device=x.device)
     packed = ffn_k256_packed_weights(w1, w2)
-    st = _lib.load().rdetr_ffn_ln_k256_bf16(x.data_ptr(), ldx, packed.data_ptr(), b1.contiguous().data_ptr(), b2.contiguous().data_ptr(),
-                                            gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(), float(eps),
+    st = _lib.load().rdetr_ffn_ln_k256_bf16(x.data_ptr(), ldx, packed.data_ptr(), _cptr(b1), _cptr(b2),
+                                            _cptr(gamma), _cptr(beta), float(eps),
                                             None if pos is None else pos.data_ptr(), ldp, rows, F, out.data_ptr(), ldo,
                                             None if out2 is None else out2.data_ptr(), 256, _stream_ptr(x))
     _lib.check(st, "rdetr_ffn_ln_k256_bf16")
@@ -1192,8 +1207,8 @@ def linear_ln_k256(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
             torch.cuda.current_stream(weight.device).synchronize()
         return packed
     packed_w = _LINEAR_PACKED.get((weight,), build)
-    st = lib.rdetr_linear_ln_k256_bf16(x.data_ptr(), ldx, packed_w.data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
-                                       residual.data_ptr(), ldr, gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(),
+    st = lib.rdetr_linear_ln_k256_bf16(x.data_ptr(), ldx, packed_w.data_ptr(), None if bias is None else _cptr(bias),
+                                       residual.data_ptr(), ldr, _cptr(gamma), _cptr(beta),
                                        float(eps), rows, out.data_ptr(), ldo, _stream_ptr(x))
     _lib.check(st, "rdetr_linear_ln_k256_bf16")
     return out

@@ -209,3 +209,18 @@ def test_options_object():
     assert all(m.options.rel_fused and not m.options.box_head for m in net.modules() if hasattr(m, "options"))
     for mod in (transformer, ms_deform_attn):
         assert "os.environ" not in inspect.getsource(mod)
+
+
+def test_contiguous_copies_of_small_operands_stay_referenced():
+    """ops._cptr: a contiguous tensor is passed through; a copy made for a strided one is kept referenced past the expression
+    that asked for its pointer (the launch reading it is enqueued after ALL arguments are evaluated)."""
+    import gc
+    from relation_detr_amd import ops
+    t = torch.arange(8, dtype=torch.float32)
+    assert ops._cptr(t) == t.data_ptr()
+    before = len(ops._KEEP)
+    p = ops._cptr(t[::2])
+    gc.collect()
+    assert p != t.data_ptr() and len(ops._KEEP) == min(before + 1, ops._KEEP.maxlen)
+    kept = ops._KEEP[-1]
+    assert kept.data_ptr() == p and kept.is_contiguous() and torch.equal(kept, t[::2])

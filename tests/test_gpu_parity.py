@@ -451,7 +451,8 @@ def test_full_size_properties(rd):
 
 # ------------------------------------------------------------------------------------------ fused producer
 @pytest.mark.parametrize("L,ref_dim,dtype", [(4, 2, torch.float32), (4, 4, torch.float32), (5, 2, torch.float32),
-                                             (3, 4, torch.float32), (4, 2, torch.bfloat16), (4, 4, torch.bfloat16)])
+                                             (3, 4, torch.float32), (4, 2, torch.bfloat16), (4, 4, torch.bfloat16),
+                                             (5, 2, torch.bfloat16), (5, 4, torch.bfloat16), (5, 4, torch.float32)])
 def test_msda_fused_producer_matches_unfused(rd, L, ref_dim, dtype):
     """softmax + location arithmetic inside the kernel == the reference's materialised sequence
     (ms_deform_attn.py:322-349) followed by the plain operator / the oracle."""
@@ -675,3 +676,49 @@ def test_msda_fused_row_strided_value(with_mask):
         got = ops.ms_deform_attn_forward_fused(view, shp.to(DEV), start.to(DEV), off, lg, ref, mask)
         want = ops.ms_deform_attn_forward_fused(view.contiguous(), shp.to(DEV), start.to(DEV), off, lg, ref, mask)
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_msda_five_level_bf16_input_paths_agree(rd, ref_dim):
+    """The 5-level bf16 kernel loads a lane's five consecutive points with vector loads (a lane's points span two levels: two sets
+    of level constants and reference points per lane, csrc/msda_fwd.hip kSpan); inputs that miss its alignment take the run-time-L
+    kernel with narrow loads.  Contiguous producer tensors and column slices of one packed projection output give the same bits
+    (with and without the in-kernel padding mask, Nq not a multiple of the wave's 16 queries); the run-time-L kernel agrees to a
+    bf16 rounding (it sums the softmax denominator in another order), and so does the generic kernel for the operator form."""
+    from relation_detr_amd import ops
+    shapes_l = [(23, 37), (12, 19), (6, 10), (3, 5), (2, 3)]
+    shp, start, S = pyramid(shapes_l)
+    shp, start = shp.to(DEV), start.to(DEV)
+    g = torch.Generator().manual_seed(500 + ref_dim)
+    B, Nq, L, H = 2, 77, 5, 8
+    value = torch.randn(B, S, H, 32, generator=g).to(torch.bfloat16).to(DEV)
+    packed = (torch.randn(B, Nq, 3 * H * L * 4, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    off = packed[..., :H * L * 8].view(B, Nq, H, L, 4, 2)
+    lg = packed[..., H * L * 8:].view(B, Nq, H, L * 4)
+    ref = torch.rand(B, Nq, L, 2, generator=g)
+    if ref_dim == 4:
+        ref = torch.cat([ref, torch.rand(B, Nq, L, 2, generator=g) * 0.5 + 0.02], -1)
+    ref = ref.to(DEV)
+    mask = (torch.rand(B, S, generator=g) < 0.25).to(DEV)
+
+    def misaligned(t):                       # same numbers at an address that is 4 (mod 16): the run-time-L kernel
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+        view = buf[1:].view(t.shape)
+        view.copy_(t)
+        assert view.data_ptr() % 16 == 4 and view.is_contiguous()
+        return view
+    for m in (None, mask):
+        fast = ops.ms_deform_attn_forward_fused(value, shp, start, off, lg, ref, m)
+        dense = ops.ms_deform_attn_forward_fused(value, shp, start, off.contiguous(), lg.contiguous(), ref, m)
+        slow = ops.ms_deform_attn_forward_fused(value, shp, start, off.contiguous(), lg.contiguous(), misaligned(ref), m)
+        assert torch.equal(fast, dense)
+        # the run-time-L kernel deals the points to the lanes differently: the softmax denominator is summed in another order
+        err = (fast.float() - slow.float()).abs()
+        assert (err <= 2.0 ** -8 * fast.float().abs() + 1e-3).all() and (err > 0).float().mean().item() < 0.05
+    # operator form (materialised fp32 locations / weights): vector loads vs the generic kernel (location tensor at 4 mod 8)
+    loc = torch.rand(B, Nq, H, L, 4, 2, generator=g).to(DEV) * 1.2 - 0.1
+    w = torch.softmax(torch.randn(B, Nq, H, L * 4, generator=g), -1).view(B, Nq, H, L, 4).to(DEV).contiguous()
+    a = rd.ms_deform_attn_forward(value, shp, start, loc, w, 64)
+    b = rd.ms_deform_attn_forward(value, shp, start, misaligned(loc), w, 64)
+    err = (a.float() - b.float()).abs()
+    assert (err <= 2.0 ** -8 * a.float().abs() + 1e-3).all()          # the generic kernel sums in another order

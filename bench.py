@@ -468,7 +468,7 @@ def main():
     if args.dtype == "fp32" and nstreams > 1 and os.environ.get("RDETR_BENCH_FP32_GROUPS_UNSAFE") != "1":
         raise SystemExit("[bench] fp32 runs as one image group (two fp32 groups side by side hang on this image, DESIGN.md 5)")
 
-    def make_runner(queries, net_dtype, inputs):
+    def make_runner(queries, net_dtype, inputs, groups=None):
         """(callable, launch mode) of the whole stack + top-300 detections for one network configuration."""
         net = build_network(queries, 0, num_levels=L).to(dev).to(net_dtype)           # same weights on every rank
 
@@ -477,7 +477,7 @@ def main():
             classes, coords = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))[:2]
             return select_detections(classes[-1].float(), coords[-1].float(), t[3 * L])
 
-        fwd = ImageGroups(forward_images, nstreams, device=dev)
+        fwd = ImageGroups(forward_images, groups or nstreams, device=dev)
         if not args.no_graph:                               # same kernels, one hipGraph launch per batch (graph.py)
             try:
                 return GraphedCall(fwd, inputs), "hipGraph replay"
@@ -548,6 +548,39 @@ def main():
             del run300
         except RuntimeError as e:
             print(f"[bench] 300-query variant skipped ({type(e).__name__}: {str(e)[:160]})", file=sys.stderr)
+    # * serving headroom: TWO batches of B images in flight (two graphs on two streams, consecutive batches alternate between
+    #   them), so that one batch's decoder -- a latency chain that leaves the chip idle -- overlaps the next batch's encoder.
+    #   Whole-job throughput only: a batch's latency doubles.  Never `value`: that stays one batch per step.
+    value_two_in_flight = None
+    if extras and args.dtype == "bf16" and launch == "hipGraph replay":
+        try:
+            note("two batches in flight")
+            f2, m2, p2 = build_pyramid(B, dev, seed=2000 + rank, dtype=dtype, shapes=cfg["shapes"])
+            flat2 = [*f2, *m2, *p2, sizes]
+            # each batch as ONE image group: with two batches in flight the streams already are the groups (two graphs of two
+            # groups each: 953 images/s, below `value`; two graphs of one group: 1,112 -- tools/exp_chain_overlap.py)
+            run1, _ = make_runner(Nq, dtype, flat_inputs, groups=1)
+            run2, _ = make_runner(Nq, dtype, flat2, groups=1)
+            lanes = ((run1, flat_inputs, torch.cuda.Stream(device=dev)), (run2, flat2, torch.cuda.Stream(device=dev)))
+            for _, _, s_ in lanes:
+                s_.wait_stream(torch.cuda.current_stream())
+
+            def batches(n):
+                for i in range(n):
+                    r_, f_, s_ = lanes[i % 2]
+                    with torch.cuda.stream(s_):
+                        r_(*f_)
+            nb = 2 * max(5, args.steps // 2)
+            batches(nb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batches(nb)
+            torch.cuda.synchronize()
+            value_two_in_flight = B * nb / (time.perf_counter() - t0)
+            del run1, run2, lanes
+        except RuntimeError as e:
+            print(f"[bench] two-batches-in-flight variant skipped ({type(e).__name__}: {str(e)[:160]})", file=sys.stderr)
+            torch.cuda.synchronize()
     if extras and args.dtype == "bf16":
         # In a CHILD process: the same script with --dtype fp32 on the same synthetic images (same seeds), its detections dumped
         # for the comparison (enqueued from Python: see the fp32 note at the top of main).  A child that does not finish is
@@ -602,7 +635,7 @@ def main():
             "value": world * B * args.steps / el, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "value_300_queries": value_300, "value_gemm_tuned": value_tuned,
+            "value_300_queries": value_300, "value_gemm_tuned": value_tuned, "value_two_batches_in_flight": value_two_in_flight,
             "world_size_seen": dist.get_world_size() if use_dist else 1,
             "per_rank_images_per_s": [B * args.steps / t for t in per_rank],
             "config": {"workload": f"{cfg['name']} transformer stack from feature pyramids: 6 encoder "
@@ -610,7 +643,9 @@ def main():
                                    "self-attn + MSDA cross-attn + box refinement) + top-300 detections; backbone/neck excluded",
                        "batch_per_gpu": B, "global_batch": B * world, "queries": Nq,
                        "queries_note": "value: 900 two-stage queries (what the reference config runs), 300 detections kept; "
-                                       "value_300_queries: 300 two-stage queries (BASELINE.json's wording)",
+                                       "value_300_queries: 300 two-stage queries (BASELINE.json's wording); "
+                                       "value_two_batches_in_flight: the same batches with two of them in flight on two streams "
+                                       "(serving throughput, a batch's latency doubles) -- informational, never `value`",
                        "weights": "random init (seeded); MSDA offset / attention projections N(0, .02) / N(0, .05), class heads x3, "
                                   "last box-head layers N(0, .01), tgt_embed rows equal -- see build_network",
                        "levels": L, "fp32_images_per_s": fp32_ips, "bf16_vs_fp32_detections": drift,

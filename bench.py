@@ -186,9 +186,9 @@ def pmc_traffic(dtype_name, B, config="r50"):
     of this kernel (tools/profile_msda.py -> profiles/r02/pmc_msda_fwd_B4_encoder.json) TOGETHER with the commit it was
     taken at; `traffic` is null when no pass of the current default kernel is on file.
     traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE doubled as the guide prescribes for gfx950."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_msda_fwd_B4_encoder.json") for r in ("r03", "r02"))
-                 if os.path.exists(q)), None)
-    if B != 4 or path is None or config != "r50":
+    name, batch = ("pmc_msda_fwd_B4_encoder.json", 4) if config == "r50" else ("pmc_msda_fwd_B2_focalnet.json", 2)
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, name) for r in ("r03", "r02")) if os.path.exists(q)), None)
+    if B != batch or path is None:
         return {"traffic": None}
     rec = json.load(open(path))
     c = rec.get("per_launch_mean", {}).get(dtype_name)

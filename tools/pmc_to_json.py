@@ -11,6 +11,7 @@ from collections import defaultdict
 
 def main():
     root, commit = sys.argv[1], sys.argv[2]
+    config = sys.argv[3] if len(sys.argv) > 3 else "r50"
     acc = defaultdict(list)
     for path in glob.glob(root + "/pmc_*/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
@@ -19,15 +20,18 @@ def main():
     mean = {k: sum(v) / len(v) for k, v in sorted(acc.items())}
     f, w = mean["FETCH_SIZE"], mean["WRITE_SIZE"]
     json.dump({
-        "kernel": "msda_fwd_qrun_kernel<bf16, L=4, FUSED=false>, head-major value [B,H,S,D] (the benched roofline kernel), "
-                  "encoder shape B=4 S=Nq=22323 L=4",
+        "kernel": ("msda_fwd_qrun_kernel<bf16, L=4, FUSED=false>, head-major value [B,H,S,D] (the benched roofline kernel), "
+                   "encoder shape B=4 S=Nq=22323 L=4") if config == "r50" else
+                  ("msda_fwd_qrun_kernel<bf16, L=5, FUSED=false>, head-major value [B,H,S,D] (the roofline kernel of --config focalnet), "
+                   "encoder shape B=2 S=Nq=204098 L=5"),
         "commit": commit,
-        "command": "rocprofv3 --pmc <one group per pass> -- python3 tools/profile_win.py bhsd 6 direct   (tools/final_refresh.sh)",
+        "command": "rocprofv3 --pmc <one group per pass> -- python3 tools/profile_win.py bhsd 6 direct" + ("" if config == "r50" else " focalnet"),
         "per_launch_mean": {"bf16": mean},
         "launches_per_pass": {k: len(v) for k, v in sorted(acc.items())},
         "notes": "FETCH_SIZE / WRITE_SIZE in KiB, each in its own pass; TCP_TCC_READ_REQ in requests; *_sum and SQ_* summed over "
                  "the chip. HBM traffic per launch = 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section) + "
-                 "WRITE_SIZE = %.1f MB against 228.6 MB algorithmic (raw sum %.1f MB)" % ((2 * f + w) * 1024 / 1e6, (f + w) * 1024 / 1e6),
+                 "WRITE_SIZE = %.1f MB against %s MB algorithmic (raw sum %.1f MB)" % ((2 * f + w) * 1024 / 1e6, "228.6" if config == "r50" else "1201.7",
+                                                                                      (f + w) * 1024 / 1e6),
     }, sys.stdout, indent=1)
     print()
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run only the LDS-window MSDA kernel at the encoder shape of BASELINE.json configs[1] (B=4, S=Nq=22,323, 4 levels), so that
 rocprofv3 traces / PMC passes of it stay small.
-    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/profile_win.py [bhsd|bshd] [reps] [fused]
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/profile_win.py [bhsd|bshd] [reps] [window|direct|auto] [r50|focalnet]
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES ... --output-format csv -d gpurun_out/y -- python3 tools/profile_win.py"""
 import os
 import sys
@@ -19,7 +19,8 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     algo = sys.argv[3] if len(sys.argv) > 3 else "window"
     dev = torch.device("cuda", 0)
-    value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(4, dev, torch.bfloat16)
+    cfg = bench.CONFIGS[sys.argv[4]] if len(sys.argv) > 4 else bench.CONFIGS["r50"]          # [config]: r50 (B = 4) | focalnet (B = 2)
+    value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(cfg["batch"], dev, torch.bfloat16, cfg["shapes"])
     v = value.permute(0, 2, 1, 3).contiguous() if lay == "bhsd" else value
     for _ in range(reps):
         ops.ms_deform_attn_forward(v, shapes, start, loc, attn, value_layout=lay, algo=algo)

@@ -112,6 +112,23 @@ def levels_window_ok(spatial_shapes: torch.Tensor, level_start_index: torch.Tens
     return hit
 
 
+_host_array_cache: dict = {}
+
+
+def _host_level_arrays(spatial_shapes: torch.Tensor, level_start_index: torch.Tensor):
+    """ctypes int64 arrays of the cached host copy of the level table (the tile kernel's entry points take HOST pointers)."""
+    import ctypes
+    key = host_levels(spatial_shapes, level_start_index)
+    hit = _host_array_cache.get(key)
+    if hit is None:
+        shapes, starts = key
+        hit = ((ctypes.c_int64 * (2 * len(shapes)))(*[v for hw in shapes for v in hw]), (ctypes.c_int64 * len(starts))(*starts))
+        if len(_host_array_cache) > 256:
+            _host_array_cache.clear()
+        _host_array_cache[key] = hit
+    return hit
+
+
 def _msda_algo(algo: str, spatial_shapes, level_start_index, num_value: int) -> int:
     """'auto' may take the window kernel only for a level table that meets its precondition; an explicit 'window' on one
     that does not is refused (it would leave output rows unwritten)."""
@@ -158,11 +175,18 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_loc")
     if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
         raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
-    if algo not in ("auto", "direct", "window"):
-        raise ValueError("algo must be 'auto', 'direct' or 'window'")
+    if algo not in ("auto", "direct", "window", "tile"):
+        raise ValueError("algo must be 'auto', 'direct', 'window' or 'tile'")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if value.dtype == torch.bfloat16 and algo == "tile":
+        hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
+        st = lib.rdetr_msda_forward_tile_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, hs, st_h,
+                                              sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, H, D, L, Nq, P,
+                                              out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_tile_bf16")
+        return out
     if value.dtype == torch.bfloat16:
         st = lib.rdetr_msda_forward_opt_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD,
                                              spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),

@@ -149,6 +149,13 @@ int rdetr_msda_forward_opt_bf16(const uint16_t *value, int value_layout, const i
 int rdetr_msda_forward_tile_bf16(const uint16_t *value, int value_layout, const int64_t *host_spatial_shapes,
                                  const int64_t *host_level_start_index, const float *sampling_loc, const float *attn_weight,
                                  int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
+/* The same operator on the SWEEP kernel (csrc/msda_sweep.hip, round 4): one persistent workgroup per CU slides ring-buffer
+ * windows of all four levels along a band of level-0 rows, 8 columns per step; only the new columns are fetched (LDS-DMA, a step
+ * ahead), one barrier per step.  Arguments, precondition and error behaviour as rdetr_msda_forward_tile_bf16; additionally
+ * sampling_loc must be 16-byte and attn_weight 8-byte aligned. */
+int rdetr_msda_forward_sweep_bf16(const uint16_t *value, int value_layout, const int64_t *host_spatial_shapes,
+                                  const int64_t *host_level_start_index, const float *sampling_loc, const float *attn_weight,
+                                  int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
 int rdetr_msda_forward_fused_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
                                       const int64_t *level_start_index, const uint16_t *sampling_offsets, int ld_offsets,
                                       const uint16_t *attn_logits, int ld_logits, const float *reference_points, int ref_dim,

@@ -175,17 +175,17 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_loc")
     if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
         raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
-    if algo not in ("auto", "direct", "window", "tile"):
-        raise ValueError("algo must be 'auto', 'direct', 'window' or 'tile'")
+    if algo not in ("auto", "direct", "window", "tile", "sweep"):
+        raise ValueError("algo must be 'auto', 'direct', 'window', 'tile' or 'sweep'")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
-    if value.dtype == torch.bfloat16 and algo == "tile":
+    if value.dtype == torch.bfloat16 and algo in ("tile", "sweep"):
         hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
-        st = lib.rdetr_msda_forward_tile_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, hs, st_h,
-                                              sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, H, D, L, Nq, P,
-                                              out.data_ptr(), _stream_ptr(value))
-        _lib.check(st, "rdetr_msda_forward_tile_bf16")
+        fn = lib.rdetr_msda_forward_tile_bf16 if algo == "tile" else lib.rdetr_msda_forward_sweep_bf16
+        st = fn(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, hs, st_h, sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_%s_bf16" % algo)
         return out
     if value.dtype == torch.bfloat16:
         st = lib.rdetr_msda_forward_opt_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD,

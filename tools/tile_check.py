@@ -14,6 +14,7 @@ import bench  # noqa: E402
 from relation_detr_amd import ops  # noqa: E402
 
 DEV = torch.device("cuda", 0)
+ALGO = os.environ.get("ALGO", "sweep")
 
 
 def timed(fn, reps, warm=20):
@@ -44,7 +45,7 @@ def parity():
         v = value.to(DEV)
         direct = ops.ms_deform_attn_forward(v, *rest, algo="direct").float()
         for layout, vv in (("bshd", v), ("bhsd", tw._head_major(v))):
-            out = ops.ms_deform_attn_forward(vv, *rest, value_layout=layout, algo="tile").float()
+            out = ops.ms_deform_attn_forward(vv, *rest, value_layout=layout, algo=ALGO).float()
             torch.cuda.synchronize()
             err = (out - direct).abs()
             bad = err > 2.0 ** -7 * direct.abs() + 1e-3
@@ -68,8 +69,8 @@ def main():
     arms = {
         "direct bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="direct"),
         "tile   bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="tile"),
-        "tile   bshd": lambda: ops.ms_deform_attn_forward(value, shapes, start, loc, attn, algo="tile"),
-        "window bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="window"),
+        "sweep  bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="sweep"),
+        "sweep  bshd": lambda: ops.ms_deform_attn_forward(value, shapes, start, loc, attn, algo="sweep"),
     }
     outs = {k: f().float() for k, f in arms.items()}
     ref = outs["direct bhsd"]

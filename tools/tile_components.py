@@ -16,14 +16,15 @@ from relation_detr_amd import _lib, ops  # noqa: E402
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-    setdbg = ctypes.CDLL(_lib.LIB_PATH).rdetr_dev_set_tile_dbg
+    algo = os.environ.get("ALGO", "sweep")
+    setdbg = getattr(ctypes.CDLL(_lib.LIB_PATH), "rdetr_dev_set_%s_dbg" % algo)
     dev = torch.device("cuda", 0)
     value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(4, dev, torch.bfloat16)
     vh = value.permute(0, 2, 1, 3).contiguous()
-    run = lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="tile")
+    run = lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo=algo)
     for _ in range(200):
         run()
-    for mask in (0, 7, 7 + 8, 7 + 16, 7 + 8 + 16, 7 + 32, 7 + 8 + 16 + 32, 63, 0):
+    for mask in [int(x) for x in os.environ.get("MASKS", "0,1,2,3,4,7,15,23,31,0").split(",")]:
         setdbg(mask)
         for _ in range(20):
             run()

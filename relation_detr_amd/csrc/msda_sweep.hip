@@ -38,15 +38,17 @@ typedef __bf16 sw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sw_bf16x2 __attribute__((ext_vector_type(2)));
 typedef short sw_s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kSwThreads = 512;
-constexpr int kSwWaves = kSwThreads / kWave;                  // 8 = octets per step
+constexpr int kSwThreads = 1024;
+constexpr int kSwWaves = kSwThreads / kWave;                  // 16 = quartets per step
+constexpr int kSwQ = 4;                                       // queries per wave and step
 constexpr int kSwTW = 8;                                      // level-0 columns per step
 constexpr int kSwMaxTH = 6;                                   // level-0 rows per band
 constexpr int kSwHeads = 8, kSwHeadDim = 32, kSwPoints = 4, kSwLevels = 4;
 constexpr int kSwMargin = 8;
+constexpr int kSwFlagCap = 4;                                 // flagged samples a wave keeps in flight per step
 // rings: columns (even, so that a wrapped neighbour column keeps the bank phase) and rows per column (== 2 mod 4: the column
 // stride is == 128 mod 256 bytes, the four corners of a sample fall on four bank groups)
-constexpr int kSwRW0 = 32, kSwRW1 = 26, kSwRW2 = 22, kSwRW3 = 20;
+constexpr int kSwRW0 = 32, kSwRW1 = 24, kSwRW2 = 20, kSwRW3 = 18;
 constexpr int kSwCR0 = 22, kSwCR1 = 22, kSwCR2 = 22, kSwCR3 = 18;
 __host__ __device__ constexpr int sw_rw(int l) { return l == 0 ? kSwRW0 : l == 1 ? kSwRW1 : l == 2 ? kSwRW2 : kSwRW3; }
 __host__ __device__ constexpr int sw_cr(int l) { return l == 0 ? kSwCR0 : l == 1 ? kSwCR1 : l == 2 ? kSwCR2 : kSwCR3; }
@@ -55,12 +57,12 @@ __host__ __device__ constexpr int sw_cr(int l) { return l == 0 ? kSwCR0 : l == 1
 constexpr int kSwZeroOff = 0;                                 // 1 KiB of zeros: the zero sample (TL 0, BL 64, TR 128, BR 192) and what
 constexpr int kSwZeroKOff = 512 + 32;                         // idle A-operand lanes read
 constexpr int kSwWaveOff = 1024;                              // per-wave area:
-constexpr int kSwStageW = 0;                                  //   [0, 512)      W[query 8][part 2][point 4][corner 4] bf16
-constexpr int kSwStageO = 512;                                //   [512, 1024)   O[corner 4: TL TR BL BR][query 8][point 4] u32: LDS address of that corner's row
-constexpr int kSwPatch = 1024;                                //   [1024, 2048)  4 patch cells of 256 B: [TL 64][BL 64][TR 64][BR 64]
-constexpr int kSwFgo = 2048;                                  //   [2048, 2112)  packed pixels of the flagged samples in flight
-constexpr int kSwWaveBytes = 2176;
-constexpr int kSwRing0 = kSwWaveOff + kSwWaves * kSwWaveBytes;                       // 18432
+constexpr int kSwStageW = 0;                                  //   [0, 1024)     W[query 4][part 2][level 4][point 4][corner 4] bf16
+constexpr int kSwStageO = 1024;                               //   [1024, 1536)  O[side 2: left, right][query 4][level 4][point 4] u32:
+                                                              //                 LDS address of the sample's top corner on that side
+constexpr int kSwFgo = 1536;                                  //   [1536, 1792)  flagged samples in flight x {pixel, slot, 4 weights, -, -}
+constexpr int kSwWaveBytes = 1792;
+constexpr int kSwRing0 = kSwWaveOff + kSwWaves * kSwWaveBytes;                       // 29696
 constexpr int kSwRing1 = kSwRing0 + kSwRW0 * kSwCR0 * 64;
 constexpr int kSwRing2 = kSwRing1 + kSwRW1 * kSwCR1 * 64;
 constexpr int kSwRing3 = kSwRing2 + kSwRW2 * kSwCR2 * 64;
@@ -114,30 +116,15 @@ __device__ __forceinline__ void sw_wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
-__device__ __forceinline__ void sw_wait_vm(int n)
+// x + (x rotated by N lanes inside its row of 16 lanes)
+template <int N> __device__ __forceinline__ float sw_row_ror_add(float x)
 {
-    switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;        // more than expected in flight: drain (always safe)
-    }
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
 }
 
 // HM = false: value [B,S,H,D] (the reference operator's layout); HM = true: value [B,H,S,D] (head-major).
 template <bool HM>
-__global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
+__global__ __launch_bounds__(kSwThreads, 4) void msda_fwd_sweep_kernel(
     const uint16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn, const SweepLevels lv,
     int S, int nb, int steps_x, int total_steps, int nblk, int dbg, uint16_t *__restrict__ out)
 {
@@ -168,17 +155,15 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
     if (tid < 256) reinterpret_cast<unsigned *>(lds + kSwZeroOff)[tid] = 0u;      // published by the first barrier
 
     // ---- lane roles ---------------------------------------------------------------------------------------------------------
-    // set-up: query qi of the octet, level sl, point pair hf (points 2 hf, 2 hf + 1)
-    const int qi = lane >> 3, sl = (lane >> 1) & 3, hf = lane & 1;
-    // gather: K-group kg, corner tq / piece tp of a transposed read; as an A-operand lane: row am = lane & 15 =
-    // 8 * (quad half ah) + 2 * (K-group ag) + (0 = bf16 high part, 1 = low part)
+    // set-up: ONE sample per lane -- query qi of the wave's quartet, level sl, point pp
+    const int qi = lane >> 4, sl = (lane >> 2) & 3, pp = lane & 3;
+    // gather: K-group kg (= query kg), corner tq / piece tp of a transposed read; as an A-operand lane: row am = lane & 15 =
+    // 2 * (query ag) + (0 = bf16 high part, 1 = low part), rows 8..15 unused
     const int kg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-    const int am = lane & 15, ah = am >> 3, ag = (am >> 1) & 3, apart = am & 1;
+    const int am = lane & 15, ag = am >> 1, apart = am & 1;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;     // 0 in practice
     const unsigned wave_off = (unsigned)(kSwWaveOff + wave * kSwWaveBytes);
     unsigned char *const wreg = lds + wave_off;
-    int *const fgo = reinterpret_cast<int *>(wreg + kSwFgo);
-    const unsigned cell0 = __builtin_amdgcn_readfirstlane(lds0 + wave_off + (unsigned)kSwPatch);
     // level constants of the set-up role (level sl)
     const int myW = pick(sl, W0, W1, W2, W3), myH = pick(sl, H0, H1, H2, H3);
     const float myWf = (float)myW, myHf = (float)myH, myWc = (float)(myW + 1), myHc = (float)(myH + 1);
@@ -190,31 +175,31 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
                                                                   // K-groups of a 32-lane half never share a bank group
     const unsigned myRB = lds0 + (unsigned)(sl == 0 ? kSwRing0 : sl == 1 ? kSwRing1 : sl == 2 ? kSwRing2 : kSwRing3) + par32;
     const unsigned o_zero = lds0 + (unsigned)kSwZeroOff + par32;
-    // One MFMA step = quad half h, point pair j: K-group kg carries the two samples (points 2j, 2j + 1) of query 4 h + kg; its
-    // lane (corner tq, piece tp) reads 8 bytes of that corner's row of each
-    const unsigned cd = (unsigned)tp * 8u;
-    const unsigned o_rd = lds0 + wave_off + (unsigned)kSwStageO + (unsigned)tq * 128u + (unsigned)kg * 16u;   // + h * 64
-    const unsigned w_real = lds0 + wave_off + (unsigned)kSwStageW + (unsigned)((4 * ah + kg) * 64 + apart * 32);
-    const unsigned w_rd0 = (ag == kg && ah == 0) ? w_real : lds0 + (unsigned)kSwZeroKOff;
-    const unsigned w_rd1 = (ag == kg && ah == 1) ? w_real : lds0 + (unsigned)kSwZeroKOff;
+    // One MFMA step = level l, point pair j: K-group kg carries the two samples (points 2j, 2j + 1 of level l) of query kg;
+    // its lane (corner tq, piece tp) reads 8 bytes of that corner's row of each: O[side tq & 1] + 64 (tq >> 1) + 8 tp
+    const unsigned cd = (unsigned)tp * 8u + (unsigned)(tq >> 1) * 64u;
+    const unsigned o_rd = lds0 + wave_off + (unsigned)kSwStageO + (unsigned)(tq & 1) * 256u + (unsigned)kg * 64u;   // + l * 16
+    const unsigned w_rd = (am < 8 && ag == kg) ? lds0 + wave_off + (unsigned)kSwStageW + (unsigned)(ag * 256 + apart * 128)
+                                               : lds0 + (unsigned)kSwZeroKOff;                                      // + l * 32 + j * 16
     // staging writes of the set-up role
-    unsigned char *const st_o = wreg + kSwStageO + qi * 16 + hf * 8;              // + corner * 128
-    unsigned char *const st_w = wreg + kSwStageW + qi * 64 + hf * 16;             // + part * 32
+    unsigned char *const st_o = wreg + kSwStageO + qi * 64 + sl * 16 + pp * 4;    // + side * 256
+    unsigned char *const st_w = wreg + kSwStageW + qi * 256 + sl * 32 + pp * 8;   // + part * 128
+    // geometry role: lanes 0..3 compute cl_l(s + 3), lanes 4..6 xa_l(s + 4), l = lane - 3
+    const int geoW = lane < 4 ? pick(lane, W0, W1, W2, W3) : pick(lane - 3, W0, W1, W2, W3);
 
     auto lds_b128 = [](unsigned a) { return *(__attribute__((address_space(3))) const u32x4 *)a; };
     auto lds_tr = [](unsigned a) {
         return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sw_s16x4 *)a));
     };
 
-    // The inputs of a step -- locations of the lane's two points (x0, y0, x1, y1) and their weights -- are loaded TWO steps
-    // ahead by inline assembly into one of three register sets used in rotation: hipcc does not know these loads, so it
-    // neither waits for them nor drains the window fills in flight when it meets their first use (tracked loads cost a
-    // vmcnt(0) per step here: a full trip to HBM).  A set is complete when the step after the one that issued it ends (its
-    // counted wait names the set, so no use is scheduled above it).
-    struct Inputs { f32x4 xy; f32x2 a; };
+    // The inputs of a step -- location and weight of the lane's sample -- are loaded TWO steps ahead by inline assembly into one
+    // of three register sets used in rotation: hipcc does not know these loads, so it neither waits for them nor drains the
+    // window fills in flight when it meets their first use (tracked loads cost a vmcnt(0) per step here: a trip to HBM).  A set
+    // is complete when the step after the one that issued it ends (its counted wait names the set, so no use is scheduled above).
+    struct Inputs { f32x2 xy; float a; };
     Inputs r0, r1, r2;
-    r0.xy = r1.xy = r2.xy = f32x4{0.f, 0.f, 0.f, 0.f};
-    r0.a = r1.a = r2.a = f32x2{0.f, 0.f};
+    r0.xy = r1.xy = r2.xy = f32x2{0.f, 0.f};
+    r0.a = r1.a = r2.a = 0.f;
 
     for (int gs = g0; gs < g1;) {
         // ---- segment: consecutive steps of one band ----------------------------------------------------------------------
@@ -227,7 +212,7 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
         const int sx_end = sx0 + (left < room ? left : room);
         const int Y0 = __builtin_amdgcn_readfirstlane((int)sw_div((unsigned)(band * H0), (unsigned)nb));
         const int Y1 = __builtin_amdgcn_readfirstlane((int)sw_div((unsigned)((band + 1) * H0), (unsigned)nb));
-        const int th = Y1 - Y0;                                       // <= kSwMaxTH
+        const int th2 = 2 * (Y1 - Y0);                                // waves [0, th2): level-0 half rows; [th2, 16): coarser pixels
 
         // the (image, head) value plane behind one wave-uniform buffer descriptor; byte offsets inside it are 32-bit
         const unsigned char *plane = reinterpret_cast<const unsigned char *>(value) +
@@ -236,83 +221,98 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
         const unsigned plane_bytes = HM ? (unsigned)S * 64u : (unsigned)S * kGPixB - (unsigned)m * 64u;
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(plane), 0, plane_bytes, 0x00020000);
-        const float *loc_b = loc + ((size_t)b * Nq * kSwHeads + (size_t)m) * (kSwLevels * kSwPoints * 2) + sl * 8 + hf * 4;
-        const float *att_b = attn + ((size_t)b * Nq * kSwHeads + (size_t)m) * (kSwLevels * kSwPoints) + sl * 4 + hf * 2;
-        uint16_t *out_b = out + (size_t)b * Nq * (kSwHeads * kSwHeadDim) + m * kSwHeadDim + (lane & 3) * 8;
+        // wave-uniform bases of this (image, head); the per-lane parts are 32-bit byte offsets (one image's tensors are < 4 GB)
+        const float *loc_b = loc + ((size_t)b * Nq * kSwHeads + (size_t)m) * (kSwLevels * kSwPoints * 2);
+        const float *att_b = attn + ((size_t)b * Nq * kSwHeads + (size_t)m) * (kSwLevels * kSwPoints);
+        uint16_t *out_b = out + (size_t)b * Nq * (kSwHeads * kSwHeadDim) + m * kSwHeadDim;
 
         // rows of the band's windows, per level: [rlo, rlo + nrows); rows of the coarser pixels inside the band: [ya, ya + ny)
-        int NR[kSwLevels], YA[kSwLevels], NY[kSwLevels];
-        unsigned ROWA[kSwLevels], ROWB[kSwLevels];     // fill role: lane = (row lane >> 2 of a 16-row piece, 16-byte chunk lane & 3):
-                                                       // byte offset of the lane's row for the column's first piece (rows 0..15)
-                                                       // and its second (rows nr - 16 .. nr - 1), or "out of range"
+        int RLO[kSwLevels], NR[kSwLevels];
+        int YAv = 0, NYv = 0;                           // lane l = 1..3: first row / row count of the coarser pixels inside the band
         // ... of the lane's own level (set-up role): the same formulas on per-lane operands
         const int my_rlo = (int)sw_div((unsigned)(Y0 * myH), (unsigned)H0) - kSwMargin;
         const int my_rhi = (int)sw_div((unsigned)((Y1 - 1) * myH), (unsigned)H0) + kSwMargin;
-        const int my_nr = my_rhi - my_rlo + 1 > myCR ? myCR : my_rhi - my_rlo + 1;
+        const int my_nr1 = (my_rhi - my_rlo + 1 > myCR ? myCR : my_rhi - my_rlo + 1) - 1;
 #pragma unroll
         for (int l = 0; l < kSwLevels; ++l) {
             const int rlo = (l == 0 ? Y0 : (int)sw_div((unsigned)(Y0 * LH(l)), (unsigned)H0)) - kSwMargin;
             const int rhi = (l == 0 ? Y1 - 1 : (int)sw_div((unsigned)((Y1 - 1) * LH(l)), (unsigned)H0)) + kSwMargin;
             int nr = rhi - rlo + 1;
             nr = nr > sw_cr(l) ? sw_cr(l) : nr;
+            RLO[l] = __builtin_amdgcn_readfirstlane(rlo);
             NR[l] = __builtin_amdgcn_readfirstlane(nr);
-            const int ya = l == 0 ? Y0 : sw_first(Y0, LH(l), H0), yb = l == 0 ? Y1 : sw_first(Y1, LH(l), H0);
-            YA[l] = __builtin_amdgcn_readfirstlane(ya);
-            NY[l] = __builtin_amdgcn_readfirstlane(yb - ya);
-            const int fa = rlo + (lane >> 2), fb = rlo + nr - 16 + (lane >> 2);
-            ROWA[l] = (fa >= 0 && fa < LH(l)) ? (unsigned)(LS(l) + fa * LW(l)) * kGPixB + (unsigned)(lane & 3) * 16u : 0x80000000u;
-            ROWB[l] = (fb >= 0 && fb < LH(l)) ? (unsigned)(LS(l) + fb * LW(l)) * kGPixB + (unsigned)(lane & 3) * 16u : 0x80000000u;
+            if (l > 0) {
+                const int ya = sw_first(Y0, LH(l), H0), yb = sw_first(Y1, LH(l), H0);
+                YAv = lane == l ? ya : YAv;
+                NYv = lane == l ? yb - ya : NYv;
+            }
         }
 
-        // column geometry: cl(s) per level, xa(s) = first column whose centre lies at level-0 column 8 s or beyond (the coarser
-        // pixels of a step are [xa(s), xa(s + 1))).  Computed PER LANE for the lane's level sl (lane 2 l = level l), read as
-        // scalars by the other roles.
-        auto cl_of = [&](int s) { return sw_cl(s, myW, W0); };
-        auto xa_of = [&](int s) { const int c0 = s * kSwTW; return c0 >= W0 ? myW : sw_first(c0, myW, W0); };
-        auto lvl = [&](int v, int l) { return __builtin_amdgcn_readlane(v, 2 * l); };
+        // column geometry: cl_l(s) and xa_l(s) = first column of level l whose centre lies at level-0 column 8 s or beyond (the
+        // coarser pixels of a step are [xa(s), xa(s + 1))).  One lane-parallel evaluation gives all seven values of a step.
+        auto geometry = [&](int s) -> int {                                  // lanes 0..3: cl_lane(s); lanes 4..6: xa_(lane-3)(s)
+            const bool is_cl = lane < 4;
+            const unsigned c0 = (unsigned)(s * kSwTW);
+            const unsigned num = is_cl ? c0 * (unsigned)geoW : 2u * c0 * (unsigned)geoW + (unsigned)W0 - 1u;
+            unsigned v = sw_div(num, (unsigned)W0);
+            v = is_cl ? v : v >> 1;
+            v = (c0 >= (unsigned)W0 || v > (unsigned)geoW) ? (unsigned)geoW : v;
+            return (int)v;
+        };
 
-        // this lane's query in a step: waves [0, th) = the level-0 rows of the band, waves [th, 8) = the coarser pixels
+        // this lane's query in a step: waves [0, th2) = half a level-0 row of the step each, waves [th2, 16) = the coarser pixels
         // [xa_l, xb_l) x [YA_l, YA_l + NY_l), l = 1..3
-        auto query_of = [&](int s, const int (&xa)[kSwLevels], const int (&xb)[kSwLevels]) -> int {
-            if (wave < th) {
-                const int x = s * kSwTW + qi;
-                return x < W0 ? T0 + (Y0 + wave) * W0 + x : -1;
+        // (ga / gb = the geometry vectors of step s and s + 1)
+        auto query_of = [&](int s, int ga, int gb) -> int {
+            if (wave < th2) {
+                const int x = s * kSwTW + (wave & 1) * kSwQ + qi;
+                return x < W0 ? T0 + (Y0 + (wave >> 1)) * W0 + x : -1;
             }
-            int j = (wave - th) * 8 + qi, q = -1;
+            int j = (wave - th2) * kSwQ + qi, q = -1;
 #pragma unroll
             for (int l = 1; l < kSwLevels; ++l) {
-                const int nx = xb[l] - xa[l], n = nx * NY[l];
+                const int xa = __builtin_amdgcn_readlane(ga, l + 3), nx = __builtin_amdgcn_readlane(gb, l + 3) - xa;
+                const int ya = __builtin_amdgcn_readlane(YAv, l), n = nx * __builtin_amdgcn_readlane(NYv, l);
                 if (q < 0 && j >= 0 && j < n) {
                     const int yy = (int)sw_div((unsigned)j, (unsigned)nx);
-                    q = LS(l) + (YA[l] + yy) * LW(l) + xa[l] + (j - yy * nx);
+                    q = LS(l) + (ya + yy) * LW(l) + xa + (j - yy * nx);
                 }
                 j -= n;
             }
             return q;
         };
         auto issue_loads = [&](Inputs &r, int q) {
-            const unsigned e = (unsigned)(q >= 0 ? q : 0) * (kSwHeads * kSwLevels * kSwPoints);
-            const float *pl = loc_b + 2u * e, *pa = att_b + e;
-            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+            const unsigned e = (unsigned)(q >= 0 ? q : 0) * (kSwHeads * kSwLevels * kSwPoints) + (unsigned)(lane & 15);   // element sl * 4 + pp
+            const unsigned ol = e * 8u, oa = e * 4u;
+            asm volatile("global_load_dwordx2 %0, %2, %4\n\tglobal_load_dword %1, %3, %5"
                          : "=&v"(r.xy), "=&v"(r.a)
-                         : "v"(pl), "v"(pa)
+                         : "v"(ol), "v"(oa), "s"(loc_b), "s"(att_b)
                          : "memory");
         };
-        // s_waitcnt vmcnt(n) that also names a register set: nothing that uses the set is scheduled above the wait
-        auto wait_set = [&](int n, Inputs &r) {
+        // s_waitcnt vmcnt(n) for registers hipcc does not know to be in flight: a wait-only statement (naming the registers as
+        // operands made hipcc COPY them into the statement's operand registers ahead of the wait -- unlanded data) followed by a
+        // scheduling barrier, so that no use is moved above it
+        auto wait_vm = [&](int n) {
             switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.xy), "+v"(r.a) : : "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(r.xy), "+v"(r.a) : : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(r.xy), "+v"(r.a) : : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(3)" : "+v"(r.xy), "+v"(r.a) : : "memory"); break;
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                  // more than expected in flight: drain
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
 
         // ---- LDS-DMA of one 16-row piece of one column of level l into ring slot `slot` ---------------------------------------
         auto fill_piece = [&](int l, int c, int slot, int second) {
-            const unsigned rowoff = second ? ROWB[l] : ROWA[l];
-            const bool colok = c >= 0 && c < LW(l);
-            const unsigned voff = colok ? rowoff + (unsigned)c * kGPixB : 0x80000000u;
+            // fill role: lane = (row lane >> 2 of the 16-row piece, 16-byte chunk lane & 3); the column's first piece = rows 0..15
+            // of the window, its second = rows nr - 16 .. nr - 1
+            const int y = RLO[l] + (second ? NR[l] - 16 : 0) + (lane >> 2);
+            const bool ok = c >= 0 && c < LW(l) && y >= 0 && y < LH(l);
+            const unsigned voff = ok ? (unsigned)(LS(l) + y * LW(l) + c) * kGPixB + (unsigned)(lane & 3) * 16u : 0x80000000u;
             const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)sw_ring(l) + (unsigned)slot * (unsigned)(sw_cr(l) * 64) +
                                                                 (second ? (unsigned)(NR[l] - 16) * 64u : 0u));
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
@@ -340,151 +340,135 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
         };
 
         // ---- segment start: geometry of the first steps, inputs of the first two, warm-up fill of the whole window of sx0 -----
-        int cl0 = cl_of(sx0), cl1 = cl_of(sx0 + 1), cl2 = cl_of(sx0 + 2);    // per lane (level sl): cl(s), cl(s + 1), cl(s + 2)
-        unsigned my_slo = 0;                                                 // per lane: ring slot of column cl(s) - 8 of level sl
-        int C1[kSwLevels], C2[kSwLevels];                                    // scalars: cl(s + 1), cl(s + 2)
-        int XA2[kSwLevels], XA3[kSwLevels];                                  // scalars: xa(s + 2), xa(s + 3)
+        int V1, V2, V3;                                                      // geometry vectors of steps s + 1, s + 2, s + 3
         int slot_new[kSwLevels];                                             // scalars: ring slot of the first new column
+        int my_ca, my_cb, my_cc;                                             // per lane (level sl): cl(s), cl(s + 1), cl(s + 2)
+        unsigned my_slo = 0;                                                 // per lane: ring slot of column cl(s) - 8 of level sl
         int q0, q1;
         {
-            const int c2 = cl2, x0v = xa_of(sx0), x1v = xa_of(sx0 + 1), x2v = xa_of(sx0 + 2), x3v = xa_of(sx0 + 3);
-            int XA0[kSwLevels], XA1[kSwLevels], cf[kSwLevels], nn[kSwLevels], sf[kSwLevels];
+            const int V0 = geometry(sx0);
+            V1 = geometry(sx0 + 1); V2 = geometry(sx0 + 2); V3 = geometry(sx0 + 3);
+            int cf[kSwLevels], nn[kSwLevels], sf[kSwLevels];
 #pragma unroll
             for (int l = 0; l < kSwLevels; ++l) {
-                const int c0s = lvl(cl0, l);
-                C1[l] = lvl(cl1, l);
-                C2[l] = lvl(c2, l);
-                XA0[l] = lvl(x0v, l); XA1[l] = lvl(x1v, l); XA2[l] = lvl(x2v, l); XA3[l] = lvl(x3v, l);
-                cf[l] = c0s - kSwMargin;
-                nn[l] = C1[l] - c0s + 2 * kSwMargin;
+                const int ca = __builtin_amdgcn_readlane(V0, l);
+                cf[l] = ca - kSwMargin;
+                nn[l] = __builtin_amdgcn_readlane(V1, l) - ca + 2 * kSwMargin;
                 sf[l] = 0;
                 slot_new[l] = nn[l] >= sw_rw(l) ? nn[l] - sw_rw(l) : nn[l];
             }
-            q0 = query_of(sx0, XA0, XA1);
-            q1 = sx0 + 1 < sx_end ? query_of(sx0 + 1, XA1, XA2) : -1;
+            my_ca = __builtin_amdgcn_ds_bpermute(sl * 4, V0);                // lane l holds cl_l
+            my_cb = __builtin_amdgcn_ds_bpermute(sl * 4, V1);
+            my_cc = __builtin_amdgcn_ds_bpermute(sl * 4, V2);
+            q0 = query_of(sx0, V0, V1);
+            q1 = sx0 + 1 < sx_end ? query_of(sx0 + 1, V1, V2) : -1;
             issue_loads(r0, q0);
             issue_loads(r1, q1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                    // the previous segment's last gathers are done
             if (!(dbg & 1)) fill_columns(cf, nn, sf);
         }
-        wait_set(0, r0);
-        wait_set(0, r1);
+        wait_vm(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
         // ---- one step: `cur` = this step's inputs, `nxt` = the next step's (issued one step ago), `nn` = loaded here for sx + 2 --
         auto step = [&](int sx, Inputs &cur, Inputs &nxt, Inputs &nn) {
-            // geometry two / three steps ahead (per lane), the query of step sx + 2, its inputs on their way
-            const int cl3v = cl_of(sx + 3), xa4v = xa_of(sx + 4);
-            int XA4[kSwLevels];
-#pragma unroll
-            for (int l = 1; l < kSwLevels; ++l) XA4[l] = lvl(xa4v, l);
-            XA4[0] = 0;
-            const int q2 = sx + 2 < sx_end ? query_of(sx + 2, XA2, XA3) : -1;
+            // geometry three / four steps ahead, the query of step sx + 2 (its inputs are loaded below)
+            const int V4 = geometry(sx + 4);
+            const int q2 = sx + 2 < sx_end ? query_of(sx + 2, V2, V3) : -1;
             if (sx >= sx_end) { issue_loads(nn, -1); return; }              // keeps the rotation; uniform
-            const bool octet = __ballot(q0 >= 0) != 0ull;                    // uniform: does this wave have queries in this step?
+            const bool busy = __ballot(q0 >= 0) != 0ull;                     // uniform: does this wave have queries in this step?
             const bool next = sx + 1 < sx_end;
 
-            // ---- set-up of this lane's two samples (level sl, points 2 hf, 2 hf + 1 of query qi): msda_fwd.hip's arithmetic
+            // ---- set-up of this lane's sample (query qi, level sl, point pp): msda_fwd.hip's arithmetic
             // (ms_deform_im2col_cuda.cuh:22-73, 274-277) ----------------------------------------------------------------
-            unsigned A_[2][4];                 // LDS addresses of the four corner rows (TL, TR, BL, BR), + par32
-            unsigned WH01[2], WH23[2], WL01[2], WL23[2];
-            unsigned PK[2];
-            bool pend[2];
+            float w00, w01, w10, w11;
+            unsigned pk;
+            bool pend;
             {
-                const int c_lo = cl0 - kSwMargin, span1 = cl1 - cl0 + 2 * kSwMargin - 1;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float lxn = i ? cur.xy.z : cur.xy.x, lyn = i ? cur.xy.w : cur.xy.y, aw = i ? cur.a.y : cur.a.x;
-                    float x = lxn * myWf - 0.5f, y = lyn * myHf - 0.5f;
-                    x = fminf(fmaxf(x, -2.f), myWc);                          // NaN -> -2: outside
-                    y = fminf(fmaxf(y, -2.f), myHc);
-                    const float xf = floorf(x), yf = floorf(y);
-                    const int x0 = (int)xf, y0 = (int)yf;
-                    const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
-                    // -1 < x < W  <=>  x0 in [-1, W - 1] (x == -1 exactly weighs the outside column: contributes zero either way)
-                    const bool valid = q0 >= 0 && (unsigned)(x0 + 1) <= (unsigned)myW && (unsigned)(y0 + 1) <= (unsigned)myH;
-                    const float w00 = hy * hx * aw, w01 = hy * lx * aw, w10 = ly * hx * aw, w11 = ly * lx * aw;
-                    const int cx = x0 - c_lo, cy = y0 - my_rlo;
-                    const bool in_win = (unsigned)cx < (unsigned)span1 && (unsigned)cy < (unsigned)(my_nr - 1);
-                    const bool live = valid && in_win && !(dbg & 8);
-                    pend[i] = valid && !in_win && !(dbg & 8);
-                    PK[i] = ((unsigned)sl << 30) | ((unsigned)(y0 + 2) << 15) | (unsigned)(x0 + 2);
-                    unsigned s0 = my_slo + (unsigned)cx;
-                    s0 = s0 < s0 - myRW ? s0 : s0 - myRW;                     // wrap (s0 < 2 RW)
-                    unsigned s1 = s0 + 1u;
-                    s1 = s1 < s1 - myRW ? s1 : s1 - myRW;
-                    const unsigned rowb = myRB + (unsigned)cy * 64u;
-                    const unsigned tl = rowb + s0 * myCS, tr = rowb + s1 * myCS;
-                    A_[i][0] = live ? tl : o_zero;                          // corner order of the weights: TL, TR, BL, BR
-                    A_[i][1] = live ? tr : o_zero + 128u;
-                    A_[i][2] = live ? tl + 64u : o_zero + 64u;
-                    A_[i][3] = live ? tr + 64u : o_zero + 192u;
-                    sw_split2(w00, w01, WH01[i], WL01[i]);
-                    sw_split2(w10, w11, WH23[i], WL23[i]);
-                }
+                float x = cur.xy.x * myWf - 0.5f, y = cur.xy.y * myHf - 0.5f;
+                x = fminf(fmaxf(x, -2.f), myWc);                              // NaN -> -2: outside
+                y = fminf(fmaxf(y, -2.f), myHc);
+                const float xf = floorf(x), yf = floorf(y);
+                const int x0 = (int)xf, y0 = (int)yf;
+                const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+                // -1 < x < W  <=>  x0 in [-1, W - 1] (x == -1 exactly weighs the outside column: contributes zero either way)
+                const bool valid = q0 >= 0 && (unsigned)(x0 + 1) <= (unsigned)myW && (unsigned)(y0 + 1) <= (unsigned)myH;
+                w00 = hy * hx * cur.a; w01 = hy * lx * cur.a; w10 = ly * hx * cur.a; w11 = ly * lx * cur.a;
+                const int cx = x0 - (my_ca - kSwMargin), cy = y0 - my_rlo;
+                const bool in_win = (unsigned)cx < (unsigned)(my_cb - my_ca + 2 * kSwMargin - 1) && (unsigned)cy < (unsigned)my_nr1;
+                const bool live = valid && in_win && !(dbg & 8);
+                pend = valid && !in_win && !(dbg & 8);
+                pk = ((unsigned)sl << 30) | ((unsigned)(y0 + 2) << 15) | (unsigned)(x0 + 2);
+                unsigned s0 = my_slo + (unsigned)cx;
+                s0 = s0 < s0 - myRW ? s0 : s0 - myRW;                         // wrap (s0 < 2 RW)
+                unsigned s1 = s0 + 1u;
+                s1 = s1 < s1 - myRW ? s1 : s1 - myRW;
+                const unsigned rowb = myRB + (unsigned)cy * 64u;
+                // the staged set-up: top corners' rows on the left / right side (the bottom ones 64 B further on) and the weights
+                *reinterpret_cast<unsigned *>(st_o) = live ? rowb + s0 * myCS : o_zero;
+                *reinterpret_cast<unsigned *>(st_o + 256) = live ? rowb + s1 * myCS : o_zero + 128u;
+                unsigned h01, l01, h23, l23;
+                sw_split2(w00, w01, h01, l01);
+                sw_split2(w10, w11, h23, l23);
+                *reinterpret_cast<u32x2 *>(st_w) = u32x2{h01, h23};
+                *reinterpret_cast<u32x2 *>(st_w + 128) = u32x2{l01, l23};
             }
 
-            // ---- flagged samples: the first four of the wave get a patch cell each, their rows one LDS-DMA instruction --------
-            int cellof[2] = {-1, -1};
-            const bool any_flag = (__ballot(pend[0]) | __ballot(pend[1])) != 0ull;      // uniform
-            auto patch_dma = [&](int n) {                                    // cells [0, n) <- fgo[0 .. n)
-                sw_wave_sync();
-                const int k = lane >> 4, c4 = (lane >> 2) & 3;               // cell, corner (TL, BL, TR, BR), chunk lane & 3
-                const unsigned pk = (unsigned)fgo[k];
-                const int pl = (int)(pk >> 30);
+            // ---- flagged samples (corners not all inside the ring window): their four corner rows come straight from global
+            // memory into REGISTERS, 4 samples per load instruction (lane = sample lane >> 4, corner (lane >> 2) & 3: TL BL TR BR,
+            // 16-byte chunk lane & 3), and are added in fp32 at the end of the step ----------------------------------------------
+            const unsigned long long fm = __ballot(pend);
+            const int nflag = __builtin_popcountll(fm);                      // uniform
+            int *const fgo = reinterpret_cast<int *>(wreg + kSwFgo);
+            u32x4 F0 = {0u, 0u, 0u, 0u};
+            auto flag_offset = [&](int slot_i, int count) -> unsigned {      // this lane's byte offset for flagged sample slot_i
+                const int c4 = (lane >> 2) & 3;
+                const unsigned p = (unsigned)fgo[slot_i * 8];
+                const int pl = (int)(p >> 30);
                 const int pw = pick(pl, W0, W1, W2, W3), ph = pick(pl, H0, H1, H2, H3), ps = pick(pl, T0, T1, T2, T3);
-                const int xx = (int)(pk & 0x7fffu) - 2 + (c4 >> 1), yy = (int)((pk >> 15) & 0x7fffu) - 2 + (c4 & 1);
-                const bool ok = k < n && (unsigned)xx < (unsigned)pw && (unsigned)yy < (unsigned)ph;
-                const unsigned go = ok ? (unsigned)(ps + yy * pw + xx) * kGPixB + (unsigned)(lane & 3) * 16u : 0x80000000u;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             :
-                             : "s"(cell0), "v"(go), "s"(rsrc)
-                             : "memory", "m0");
+                const int xx = (int)(p & 0x7fffu) - 2 + (c4 >> 1), yy = (int)((p >> 15) & 0x7fffu) - 2 + (c4 & 1);
+                const bool ok = slot_i < count && (unsigned)xx < (unsigned)pw && (unsigned)yy < (unsigned)ph;
+                return ok ? (unsigned)(ps + yy * pw + xx) * kGPixB + (unsigned)(lane & 3) * 16u : 0x80000000u;
             };
-            auto assign_cells = [&]() -> int {                               // up to four pending samples -> cells; returns how many
-                const unsigned long long f0 = __ballot(pend[0]), f1 = __ballot(pend[1]);
-                const int below0 = __builtin_amdgcn_mbcnt_hi((unsigned)(f0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)f0, 0));
-                const int below1 = __builtin_amdgcn_mbcnt_hi((unsigned)(f1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)f1, 0));
-                const int ra = below0 + below1, rb = ra + (pend[0] ? 1 : 0);
-                cellof[0] = cellof[1] = -1;
-                if (pend[0] && ra < 4) { cellof[0] = ra; fgo[ra] = (int)PK[0]; pend[0] = false; }
-                if (pend[1] && rb < 4) { cellof[1] = rb; fgo[rb] = (int)PK[1]; pend[1] = false; }
-                const int n = __builtin_popcountll(f0) + __builtin_popcountll(f1);
-                return n < 4 ? n : 4;
+            auto flag_publish = [&](int first) {                             // pending samples of rank first .. first + 3 -> fgo
+                const unsigned long long f = __ballot(pend);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(f >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)f, 0)) - first;
+                if (pend && rank >= 0 && rank < kSwFlagCap) {
+                    int *e = fgo + rank * 8;
+                    e[0] = (int)pk; e[1] = qi;
+                    e[2] = __builtin_bit_cast(int, w00); e[3] = __builtin_bit_cast(int, w10);      // corner order of the loads: TL BL TR BR
+                    e[4] = __builtin_bit_cast(int, w01); e[5] = __builtin_bit_cast(int, w11);
+                }
+                sw_wave_sync();
             };
-            int vm_after_patch = 2;                                          // vector-memory instructions issued after the patch DMA
-            if (any_flag) patch_dma(assign_cells());
+            int vm_after_flag = 2;                                           // vector-memory instructions issued after the flagged load
+            if (nflag) {                                                     // uniform
+                flag_publish(0);
+                const unsigned oa = flag_offset(lane >> 4, nflag);
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(F0) : "v"(oa), "s"(rsrc) : "memory");
+            }
 
             // ---- prefetch: the new ring columns of step sx + 1, then the inputs of step sx + 2 ----------------------------------
             if (next && !(dbg & 1)) {
                 int cf[kSwLevels], nn_[kSwLevels];
 #pragma unroll
-                for (int l = 0; l < kSwLevels; ++l) { cf[l] = C1[l] + kSwMargin; nn_[l] = C2[l] - C1[l]; }
-                vm_after_patch += fill_columns(cf, nn_, slot_new);
+                for (int l = 0; l < kSwLevels; ++l) {
+                    const int cb = __builtin_amdgcn_readlane(V1, l);
+                    cf[l] = cb + kSwMargin;
+                    nn_[l] = __builtin_amdgcn_readlane(V2, l) - cb;
+                }
+                vm_after_flag += fill_columns(cf, nn_, slot_new);
             }
             issue_loads(nn, q2);
 
-            // ---- staging + MFMA rounds ---------------------------------------------------------------------------------------
+            // ---- the MFMA steps: 4 levels x 2 point pairs, software-pipelined (the operands of step s + 1 are on their way while
+            // the MFMAs of step s run) -----------------------------------------------------------------------------------------
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // D rows 4 g' + r of a lane = query 2 g' + (r >> 1), part r & 1,
-                                                                             // channel (lane & 15) + 16 ((r >> 1) ^ X)
-            auto stage = [&](bool only_patched) {
-                // lanes of the round's level write their two samples: O[corner][qi][point], W[qi][part][point][corner]
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    unsigned a0 = A_[0][c], a1 = A_[1][c];
-                    if (only_patched) {
-                        const unsigned co = (unsigned)(c & 1) * 128u + (unsigned)(c >> 1) * 64u;       // cell / zero block: TL 0, BL 64, TR 128, BR 192
-                        a0 = cellof[0] >= 0 ? cell0 + (unsigned)cellof[0] * 256u + co + par32 : o_zero + co;
-                        a1 = cellof[1] >= 0 ? cell0 + (unsigned)cellof[1] * 256u + co + par32 : o_zero + co;
-                    }
-                    *reinterpret_cast<u32x2 *>(st_o + c * 128) = u32x2{a0, a1};
-                }
-                *reinterpret_cast<u32x4 *>(st_w) = u32x4{WH01[0], WH23[0], WH01[1], WH23[1]};
-                *reinterpret_cast<u32x4 *>(st_w + 32) = u32x4{WL01[0], WL23[0], WL01[1], WL23[1]};
-            };
-            auto gather_round = [&]() {
+                                                                             // channel (lane & 15) + 16 ((r >> 1) ^ X); g' < 2
+            sw_wave_sync();
+            if (busy && !(dbg & 2)) {
                 struct Operands { u32x4 af; u32x2 x0, x1, y0, y1; };
                 auto fetch = [&](unsigned wa, unsigned oa, unsigned ob) {
                     Operands r;
@@ -497,72 +481,89 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sw_bf16x8, r.af), __builtin_bit_cast(sw_bf16x8, b0), acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sw_bf16x8, r.af), __builtin_bit_cast(sw_bf16x8, b1), acc1, 0, 0, 0);
                 };
-                const u32x4 so0 = lds_b128(o_rd), so1 = lds_b128(o_rd + 64u);
-                Operands ra = fetch(w_rd0, so0.x + cd, so0.y + cd);
-                Operands rb = fetch(w_rd0 + 16, so0.z + cd, so0.w + cd);
+                u32x4 so0 = lds_b128(o_rd), so1 = lds_b128(o_rd + 16u);
+                Operands ra = fetch(w_rd, so0.x + cd, so0.y + cd);
+                Operands rb = fetch(w_rd + 16, so0.z + cd, so0.w + cd);
+                so0 = lds_b128(o_rd + 32u);
                 fma2(ra);
-                ra = fetch(w_rd1, so1.x + cd, so1.y + cd);
+                ra = fetch(w_rd + 32, so1.x + cd, so1.y + cd);
                 fma2(rb);
-                rb = fetch(w_rd1 + 16, so1.z + cd, so1.w + cd);
+                rb = fetch(w_rd + 48, so1.z + cd, so1.w + cd);
+                so1 = lds_b128(o_rd + 48u);
+                fma2(ra);
+                ra = fetch(w_rd + 64, so0.x + cd, so0.y + cd);
+                fma2(rb);
+                rb = fetch(w_rd + 80, so0.z + cd, so0.w + cd);
+                fma2(ra);
+                ra = fetch(w_rd + 96, so1.x + cd, so1.y + cd);
+                fma2(rb);
+                rb = fetch(w_rd + 112, so1.z + cd, so1.w + cd);
                 fma2(ra);
                 fma2(rb);
-            };
-            if (octet && !(dbg & 2)) {
-#pragma unroll 1
-                for (int l = 0; l < kSwLevels; ++l) {
-                    if (sl == l) stage(false);
-                    sw_wave_sync();
-                    gather_round();
-                    sw_wave_sync();
-                }
-                // flagged samples: their rows have landed by now (counted wait: the fills and loads issued after the patch DMA
-                // stay in flight); one extra round per level that has any
-                bool first = true;
-                while (any_flag) {                                           // uniform; a second trip only with more than four flagged
-                    if (first) sw_wait_vm(vm_after_patch); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    first = false;
-#pragma unroll 1
-                    for (int l = 0; l < kSwLevels; ++l) {
-                        const bool has = __ballot(sl == l && (cellof[0] >= 0 || cellof[1] >= 0)) != 0ull;
-                        if (has) {                                           // uniform
-                            if (sl == l) stage(true);
-                            sw_wave_sync();
-                            gather_round();
-                            sw_wave_sync();
-                        }
-                    }
-                    if ((__ballot(pend[0]) | __ballot(pend[1])) == 0ull) break;
-                    patch_dma(assign_cells());
-                }
             }
+            sw_wave_sync();
 
-            // ---- out[query][channel] = D[hi row] + D[lo row], transposed through the wave's staging area so that a lane stores
-            // 16 bytes -------------------------------------------------------------------------------------------------------
-            if (octet && !(dbg & 4)) {
-                float *tr = reinterpret_cast<float *>(wreg + kSwStageW);     // 1 KiB: 8 queries x 32 channels
-                tr[(2 * kg) * 32 + (lane & 15)] = acc0.x + acc0.y;
-                tr[(2 * kg + 1) * 32 + (lane & 15) + 16] = acc0.z + acc0.w;
-                tr[(2 * kg) * 32 + (lane & 15) + 16] = acc1.x + acc1.y;
-                tr[(2 * kg + 1) * 32 + (lane & 15)] = acc1.z + acc1.w;
+            // ---- out[query][channel] = D[hi row] + D[lo row] (+ the flagged samples), transposed through the wave's staging area
+            // so that a lane stores 16 bytes ------------------------------------------------------------------------------------
+            if (busy && !(dbg & 4)) {
+                float *tr = reinterpret_cast<float *>(wreg + kSwStageW);     // 512 B: 4 queries x 32 channels
+                if (lane < 32) {
+                    tr[(2 * kg) * 32 + (lane & 15)] = acc0.x + acc0.y;
+                    tr[(2 * kg + 1) * 32 + (lane & 15) + 16] = acc0.z + acc0.w;
+                    tr[(2 * kg) * 32 + (lane & 15) + 16] = acc1.x + acc1.y;
+                    tr[(2 * kg + 1) * 32 + (lane & 15)] = acc1.z + acc1.w;
+                }
                 sw_wave_sync();
-                // lane (query slot (lane >> 2) & 7, chunk lane & 3) stores 8 channels; the query index of slot k lives in lane 8 k
-                const int sq = __builtin_amdgcn_ds_bpermute(((lane >> 2) & 7) * 32, q0);
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(tr + ((lane >> 2) & 7) * 32 + (lane & 3) * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4 *>(tr + ((lane >> 2) & 7) * 32 + (lane & 3) * 8 + 4);
+                if (nflag) {                                                 // uniform
+                    // the loads have landed by now (counted wait: the fills and loads issued after them stay in flight)
+                    wait_vm(vm_after_flag);
+                    auto flag_add = [&](const u32x4 &F, int slot_i) {        // this lane: one corner, 8 channels of flagged sample slot_i
+                        const int c4 = (lane >> 2) & 3;
+                        const float wv = __builtin_bit_cast(float, fgo[slot_i * 8 + 2 + c4]);
+                        const int qs = fgo[slot_i * 8 + 1];
+                        float p[8];
+                        p[0] = bf16_bits_to_f32(F.x & 0xffffu) * wv; p[1] = __builtin_bit_cast(float, F.x & 0xffff0000u) * wv;
+                        p[2] = bf16_bits_to_f32(F.y & 0xffffu) * wv; p[3] = __builtin_bit_cast(float, F.y & 0xffff0000u) * wv;
+                        p[4] = bf16_bits_to_f32(F.z & 0xffffu) * wv; p[5] = __builtin_bit_cast(float, F.z & 0xffff0000u) * wv;
+                        p[6] = bf16_bits_to_f32(F.w & 0xffffu) * wv; p[7] = __builtin_bit_cast(float, F.w & 0xffff0000u) * wv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) p[e] = sw_row_ror_add<8>(sw_row_ror_add<4>(p[e]));      // over the four corners
+                        if (c4 == 0) {
+                            float *dst = tr + qs * 32 + (lane & 3) * 8;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) __hip_atomic_fetch_add(dst + e, p[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    };
+                    int done = 0;
+                    while (true) {                                           // uniform; further trips only with more than 4 flagged
+                        if ((lane >> 4) < nflag - done) flag_add(F0, lane >> 4);
+                        done += kSwFlagCap;
+                        if (done >= nflag) break;
+                        sw_wave_sync();
+                        flag_publish(done);
+                        const unsigned oa = flag_offset(lane >> 4, nflag - done);
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=&v"(F0) : "v"(oa), "s"(rsrc) : "memory");
+                    }
+                    sw_wave_sync();
+                }
+                // lane (query slot (lane >> 2) & 3, chunk lane & 3) stores 8 channels; the query index of slot k lives in lane 16 k
+                const int sq = __builtin_amdgcn_ds_bpermute(((lane >> 2) & 3) * 64, q0);
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(tr + ((lane >> 2) & 3) * 32 + (lane & 3) * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(tr + ((lane >> 2) & 3) * 32 + (lane & 3) * 8 + 4);
                 u32x4 w;
                 w.x = pack_bf16x2(lo.x, lo.y);
                 w.y = pack_bf16x2(lo.z, lo.w);
                 w.z = pack_bf16x2(hi.x, hi.y);
                 w.w = pack_bf16x2(hi.z, hi.w);
-                uint16_t *dst = out_b + (size_t)(sq >= 0 ? sq : 0) * (kSwHeads * kSwHeadDim);
-                if (lane < 32 && sq >= 0)
-                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
+                const unsigned od = (unsigned)(sq >= 0 ? sq : 0) * (kSwHeads * kSwHeadDim * 2) + (unsigned)(lane & 3) * 16u;
+                if (lane < 16 && sq >= 0)
+                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(od), "v"(w), "s"(out_b) : "memory");
                 sw_wave_sync();
                 // end of the step: the fills of step sx + 1 have landed and the NEXT step's inputs are complete (this step's loads and
                 // the store may stay in flight)
-                wait_set(3, nxt);
+                wait_vm(3);
             } else {
-                wait_set(2, nxt);
+                wait_vm(2);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -570,19 +571,15 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
             // shift the geometry pipeline
 #pragma unroll
             for (int l = 0; l < kSwLevels; ++l) {
-                const int c3 = lvl(cl3v, l);
-                int s = slot_new[l] + C2[l] - C1[l];
+                int s = slot_new[l] + __builtin_amdgcn_readlane(V2, l) - __builtin_amdgcn_readlane(V1, l);
                 slot_new[l] = s >= sw_rw(l) ? s - sw_rw(l) : s;
-                C1[l] = C2[l];
-                C2[l] = c3;
-                XA2[l] = XA3[l];
-                XA3[l] = XA4[l];
             }
-            my_slo += (unsigned)(cl1 - cl0);
+            my_slo += (unsigned)(my_cb - my_ca);
             my_slo = my_slo < my_slo - myRW ? my_slo : my_slo - myRW;
-            cl0 = cl1;
-            cl1 = cl2;
-            cl2 = cl3v;
+            my_ca = my_cb;
+            my_cb = my_cc;
+            my_cc = __builtin_amdgcn_ds_bpermute(sl * 4, V3);
+            V1 = V2; V2 = V3; V3 = V4;
             q0 = q1;
             q1 = q2;
         };
@@ -593,7 +590,7 @@ __global__ __launch_bounds__(kSwThreads, 2) void msda_fwd_sweep_kernel(
         }
         gs += sx_end - sx0;
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0.xy), "+v"(r0.a), "+v"(r1.xy), "+v"(r1.a), "+v"(r2.xy), "+v"(r2.a) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Band height for a level table (HOST copy): the largest number of level-0 rows per band, at most kSwMaxTH, such that the
@@ -621,7 +618,7 @@ static int sweep_band_height(const int64_t *shapes, int *nb_out, int *steps_x_ou
                     const long long xb = (s + 1) * kSwTW >= W0 ? W : sweep_first((s + 1) * kSwTW, W, W0);
                     n += (xb - xa) * (sweep_first(Y1, H, H0) - sweep_first(Y0, H, H0));
                 }
-                if (n > 8 * (kSwWaves - (Y1 - Y0))) ok = false;
+                if (n > kSwQ * (kSwWaves - 2 * (Y1 - Y0))) ok = false;
             }
         }
         if (ok) {

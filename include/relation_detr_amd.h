@@ -135,24 +135,20 @@ int rdetr_msda_levels_window_ok(const int64_t *host_spatial_shapes, const int64_
 int rdetr_msda_forward_opt_bf16(const uint16_t *value, int value_layout, const int64_t *spatial_shapes,
                                 const int64_t *level_start_index, const float *sampling_loc, const float *attn_weight, int B,
                                 int S, int H, int D, int L, int Nq, int P, int algo, uint16_t *out, void *stream);
-/* The bf16 operator on the TILE kernel (csrc/msda_tile.hip, round 4) -- the LDS-sourced gather for the ENCODER shape: queries
+/* The bf16 operator on the SWEEP kernel (csrc/msda_sweep.hip, round 4) -- the LDS-sourced gather for the ENCODER shape: queries
  * are the pyramid's own pixels in level_start order (Nq == S), L == 4, H == 8, D == 32, P == 4.  Replaces the kernel of
  * ms_deformable_im2col_cuda (ms_deform_im2col_cuda.cuh:226-288, 912-943) for that shape; same tensors as
  * ms_deform_attn_cuda_forward (ms_deform_attn_cuda.cu:12-72) except that the LEVEL TABLE is passed as HOST pointers: the grid
- * and the tile height are sized from it and the kernel takes it as arguments (the reference reads spatial_shapes on the host
+ * and the band height are sized from it and the kernel takes it as arguments (the reference reads spatial_shapes on the host
  * too, ms_deform_attn.py:313).  PRECONDITION as RDETR_MSDA_WINDOW (the levels tile [0, S), checked here on the host copy;
- * the caller promises that the device tensors it built sampling_loc from describe the same levels).  One 512-thread workgroup
- * = a 16 x TH tile of level-0 pixels (+ the coarser pixels inside it) of one (image, head); per sampled level a 32-pixel-wide
- * window of the value plane is copied to LDS by range-checked LDS-DMA (outside the level = zeros) and gathered from there by
- * ds_read_b64_tr_b16 into v_mfma_f32_16x16x32_bf16; samples outside their window are fetched from global memory into patch
- * cells, so results never depend on the windows.  RDETR_ERR_UNSUPPORTED for any other shape (callers use the direct kernel). */
-int rdetr_msda_forward_tile_bf16(const uint16_t *value, int value_layout, const int64_t *host_spatial_shapes,
-                                 const int64_t *host_level_start_index, const float *sampling_loc, const float *attn_weight,
-                                 int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
-/* The same operator on the SWEEP kernel (csrc/msda_sweep.hip, round 4): one persistent workgroup per CU slides ring-buffer
- * windows of all four levels along a band of level-0 rows, 8 columns per step; only the new columns are fetched (LDS-DMA, a step
- * ahead), one barrier per step.  Arguments, precondition and error behaviour as rdetr_msda_forward_tile_bf16; additionally
- * sampling_loc must be 16-byte and attn_weight 8-byte aligned. */
+ * the caller promises that the device tensors it built sampling_loc from describe the same levels).  One persistent
+ * 1024-thread workgroup per CU slides ring-buffer windows of all four levels along a band of level-0 rows, 8 columns per
+ * step: only the new columns are fetched (range-checked LDS-DMA, a step ahead: outside the level = zeros), the corner rows
+ * are gathered from LDS by ds_read_b64_tr_b16 into v_mfma_f32_16x16x32_bf16, samples outside their window are fetched from
+ * global memory and added in fp32, so results never depend on the windows.  RDETR_ERR_UNSUPPORTED for any other shape
+ * (pyramids whose coarser levels are not about half the finer ones included; callers use the direct kernel);
+ * sampling_loc must be 16-byte and attn_weight 8-byte aligned.  OPT-IN: measured slower than the direct kernel (DESIGN.md
+ * section 4.2 has the numbers and the measured ceiling of the data path). */
 int rdetr_msda_forward_sweep_bf16(const uint16_t *value, int value_layout, const int64_t *host_spatial_shapes,
                                   const int64_t *host_level_start_index, const float *sampling_loc, const float *attn_weight,
                                   int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);

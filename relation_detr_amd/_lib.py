@@ -27,7 +27,6 @@ SIGNATURES = {
     "rdetr_msda_forward_fused_ex_f32": [_vp] * 4 + [_c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_fused_ex_bf16": [_vp] * 4 + [_c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_opt_bf16": [_vp, _c_int] + [_vp] * 4 + [_c_int] * 8 + [_vp, _vp],
-    "rdetr_msda_forward_tile_bf16": [_vp, _c_int] + [_vp] * 4 + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_sweep_bf16": [_vp, _c_int] + [_vp] * 4 + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_fused_opt_bf16": [_vp, _c_int, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 8 + [_vp, _vp],
     "rdetr_msda_forward_fused_strided_bf16": [_vp, _c_ll, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],

@@ -161,7 +161,8 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
     """value [B,S,H,D] (fp32 or bf16), sampling_loc [B,Nq,H,L,P,2] fp32, attn_weight [B,Nq,H,L,P] fp32
     -> [B,Nq,H*D] in value's dtype.  ``im2col_step`` is accepted and ignored (no batch restriction).
     Not in the reference's signature (optional, bf16 only): ``value_layout="bhsd"`` for a head-major value [B,H,S,D]
-    (`value_to_head_major`), ``algo`` "auto" | "direct" | "window" to name the kernel (tests, A/B timing)."""
+    (`value_to_head_major`), ``algo`` "auto" | "direct" | "window" | "sweep" to name the kernel (tests, A/B timing; "sweep" =
+    csrc/msda_sweep.hip, opt-in, takes the cached HOST copy of the level table)."""
     _require_device(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                         sampling_loc=sampling_loc, attn_weight=attn_weight)
@@ -175,17 +176,17 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_loc")
     if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
         raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
-    if algo not in ("auto", "direct", "window", "tile", "sweep"):
-        raise ValueError("algo must be 'auto', 'direct', 'window', 'tile' or 'sweep'")
+    if algo not in ("auto", "direct", "window", "sweep"):
+        raise ValueError("algo must be 'auto', 'direct', 'window' or 'sweep'")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
-    if value.dtype == torch.bfloat16 and algo in ("tile", "sweep"):
+    if value.dtype == torch.bfloat16 and algo == "sweep":
         hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
-        fn = lib.rdetr_msda_forward_tile_bf16 if algo == "tile" else lib.rdetr_msda_forward_sweep_bf16
-        st = fn(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, hs, st_h, sampling_loc.data_ptr(),
-                attn_weight.data_ptr(), B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
-        _lib.check(st, "rdetr_msda_forward_%s_bf16" % algo)
+        st = lib.rdetr_msda_forward_sweep_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD, hs, st_h,
+                                               sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, H, D, L, Nq, P,
+                                               out.data_ptr(), _stream_ptr(value))
+        _lib.check(st, "rdetr_msda_forward_sweep_bf16")
         return out
     if value.dtype == torch.bfloat16:
         st = lib.rdetr_msda_forward_opt_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD,

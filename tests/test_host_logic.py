@@ -43,6 +43,16 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.rdetr_bias_softmax_f32(None, None, None, 0, 4, 4, None) == 0
     assert lib.rdetr_bias_softmax_f32(None, None, None, 2, 4, 4, None) == -1
     assert lib.rdetr_msda_backward_f32(*([None] * 6), 1, 10, 8, 32, 4, 5, 4, None, None, None, None) == -1
+    # the sweep kernel's entry point takes the level table as HOST pointers and refuses before any HIP call
+    shapes = (ctypes.c_int64 * 8)(64, 96, 32, 48, 16, 24, 8, 12)
+    starts = (ctypes.c_int64 * 4)(0, 6144, 7680, 8064)
+    one = ctypes.c_void_p(16)                                       # an aligned non-null dummy: never dereferenced on these paths
+    assert lib.rdetr_msda_forward_sweep_bf16(None, 0, shapes, starts, None, None, 1, 8160, 8, 32, 4, 8160, 4, None, None) == -1
+    assert lib.rdetr_msda_forward_sweep_bf16(None, 0, shapes, starts, None, None, 0, 8160, 8, 32, 4, 8160, 4, None, None) == 0
+    assert lib.rdetr_msda_forward_sweep_bf16(one, 7, shapes, starts, one, one, 1, 8160, 8, 32, 4, 8160, 4, one, None) == -1    # layout
+    assert lib.rdetr_msda_forward_sweep_bf16(one, 0, shapes, starts, one, one, 1, 8160, 8, 64, 4, 8160, 4, one, None) == -2    # head dim
+    assert lib.rdetr_msda_forward_sweep_bf16(one, 0, shapes, starts, one, one, 1, 8160, 8, 32, 4, 900, 4, one, None) == -2     # Nq != S
+    assert lib.rdetr_msda_forward_sweep_bf16(one, 0, shapes, starts, one, one, 1, 9000, 8, 32, 4, 9000, 4, one, None) == -2    # levels do not tile S
 
 
 def test_msda_module_contract(golden):

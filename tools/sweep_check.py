@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Development check of the tile kernel (csrc/msda_tile.hip): parity against the direct kernel on a few pyramids, then the
+"""Development check of the sweep kernel (csrc/msda_sweep.hip): parity against the direct kernel on a few pyramids, then the
 duration at the encoder shape of BASELINE.json configs[1] next to the direct kernel.
-    python3 tools/tile_check.py [reps] [B]"""
+    python3 tools/sweep_check.py [reps] [B]"""
 import os
 import sys
 
@@ -68,7 +68,7 @@ def main():
     alg = bench.msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2)
     arms = {
         "direct bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="direct"),
-        "tile   bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="tile"),
+        "window bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="window"),
         "sweep  bhsd": lambda: ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="sweep"),
         "sweep  bshd": lambda: ops.ms_deform_attn_forward(value, shapes, start, loc, attn, algo="sweep"),
     }

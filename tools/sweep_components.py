@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Component timing of the tile MSDA kernel with the development library (make -C relation_detr_amd/csrc dev):
-    RDETR_LIB_PATH=relation_detr_amd/librelation_detr_amd_dev.so python3 tools/tile_components.py [reps]
-dbg bits: 1 = no window fill, 2 = no gather, 4 = no output store (results are wrong with any bit set)."""
+"""Component timing of the sweep MSDA kernel with the development library (make -C relation_detr_amd/csrc dev):
+    RDETR_LIB_PATH=relation_detr_amd/librelation_detr_amd_dev.so python3 tools/sweep_components.py [reps]
+dbg bits: 1 = no ring fills, 2 = no MFMA steps, 4 = no flagged-sample adds / output store, 8 = every sample the zero sample,
+16 = (unused) (results are wrong with any bit set).  MASKS=0,1,2,... selects the runs."""
 import ctypes
 import os
 import sys

@@ -57,6 +57,8 @@ sys.path.insert(0, ROOT)
 
 R50_SHAPES = [(100, 168), (50, 84), (25, 42), (13, 21)]
 HBM_PEAK = 8.0e12           # B/s, MI355X spec (MI355X_MICROARCH.md)
+SETUP_REPLAYS = 12              # untimed replays before the contract's W warm-up steps (clock ramp after the idle capture phase)
+KERNEL_REPS = 50                # timed launches of the roofline kernel; 2 x KERNEL_REPS untimed launches right before them
 METRIC = "images/sec @ 800\u00d71333, 300 queries, R50 4-level; achieved HBM GB/s"      # BASELINE.json, verbatim
 ROOFLINE_KERNEL = ("msda_fwd_qrun_kernel<bf16, L=%d> on the head-major value [B,H,S,D] the module path's value projection writes "
                    "(encoder shape, B=%d; operator form with materialised locations / weights = SURVEY 8d's bytes)")
@@ -178,6 +180,77 @@ def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SH
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3, S, L
+
+
+def _timed_launches(fn, reps, busy=None):
+    """Average duration of `fn` from device events on the current stream: 3 launches, a synchronize, optionally `busy()` and
+    2 x reps untimed launches (sustained clocks), then reps timed ones."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    if busy is not None:
+        busy()
+        for _ in range(2 * reps):
+            fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def time_in_stack_kernel(B, dev, level_shapes=R50_SHAPES, reps=50, busy=None):
+    """The kernel instantiation the timed region really launches for the encoder's MSDA: the FUSED-producer
+    form msda_fwd_qrun_kernel<bf16, L, FUSED = true> on the head-major value -- raw bf16 offsets / logits and fp32 reference
+    points in, softmax and location arithmetic inside the kernel (relation_detr_amd/ms_deform_attn.py), at the encoder shape.
+    Returns (seconds, bytes it moves, SURVEY 8d's operator-form bytes)."""
+    import relation_detr_amd as rd
+    value, shapes, start, loc, attn, S, L = encoder_kernel_inputs(B, dev, torch.bfloat16, level_shapes)
+    vh = value.permute(0, 2, 1, 3).contiguous()
+    g = torch.Generator().manual_seed(321)
+    wh = shapes.flip(-1).float().cpu()
+    k = torch.arange(1, 5, dtype=torch.float32).view(1, 1, 1, 1, 4, 1)
+    off = (torch.randn(B, S, 8, L, 4, 2, generator=g) * k).to(torch.bfloat16).to(dev)       # pixels: the module divides by (W_l, H_l)
+    logits = torch.randn(B, S, 8, L * 4, generator=g).to(torch.bfloat16).to(dev)
+    refs = []
+    for h, w in level_shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(B, S, L, 2).contiguous().to(dev)
+    del wh, loc, attn
+    fn = lambda: rd.ops.ms_deform_attn_forward_fused(vh, shapes, start, off, logits, ref, value_layout="bhsd")
+    t = _timed_launches(fn, reps, busy)
+    moved = B * (S * 256 * 2 + S * 8 * L * 4 * 2 * 2 + S * 8 * L * 4 * 2 + S * L * 2 * 4 + S * 256 * 2)
+    return t, moved, msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2)
+
+
+def time_relation_kernels(B, dev, N=900, reps=30, busy=None):
+    """SURVEY 8d's other two named kernels at B images x N queries (relation_transformer.py:493-532, 452-461): the materialised
+    relation bias (rdetr_relation_bias_ws_f32: HBM-write bound, B * 8 * N * N * 4 bytes) and the fused decoder self-attention
+    that generates the bias inside the kernel (rdetr_relation_attention_boxes_bf16: VALU / transcendental bound, time only)."""
+    import relation_detr_amd as rd
+    g = torch.Generator().manual_seed(11)
+    def boxes():
+        return torch.cat([torch.rand(B, N, 2, generator=g), torch.rand(B, N, 2, generator=g) * 0.49 + 0.01], -1).to(dev)
+    src, tgt = boxes(), boxes()
+    w = ((torch.rand(8, 64, generator=g) * 2 - 1) * (6.0 / 72) ** 0.5).to(dev)
+    b = ((torch.rand(8, generator=g) * 2 - 1) * 0.125).to(dev)
+    t_bias = _timed_launches(lambda: rd.ops.relation_bias(src, tgt, w, b), reps, busy)
+    q = (torch.randn(B, N, 256, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    kk = (torch.randn(B, N, 256, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    v = torch.randn(B, N, 256, generator=g).to(torch.bfloat16).to(dev)
+    t_attn = _timed_launches(lambda: rd.ops.relation_attention_boxes(q, kk, v, 8, src, tgt, w, b), reps, busy)
+    return t_bias, B * 8 * N * N * 4, t_attn
+
+
+def time_sweep_kernel(B, dev, level_shapes=R50_SHAPES, reps=30, busy=None):
+    """The opt-in LDS-sourced kernel (csrc/msda_sweep.hip) on the same inputs as the roofline kernel, for the record."""
+    import relation_detr_amd as rd
+    value, shapes, start, loc, attn, S, L = encoder_kernel_inputs(B, dev, torch.bfloat16, level_shapes)
+    vh = value.permute(0, 2, 1, 3).contiguous()
+    return _timed_launches(lambda: rd.ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="sweep"), reps, busy)
 
 
 def pmc_traffic(dtype_name, B, config="r50"):
@@ -364,13 +437,14 @@ def dry_run(args, world, rank):
     ok = all_i.tolist() == list(range(world * B)) and all(bool((all_d[i] == float(i // B)).all()) for i in range(world * B))
     if rank == 0:
         print(json.dumps({
-            "metric": METRIC, "value": None, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": CONFIGS[args.config]["metric"], "value": None, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "none (dry run)", "dry_run": True, "gather_ok": ok,
             "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "per_rank_step_ms": [t / max(args.steps, 1) * 1e3 for t in per_rank],
             "config": {"workload": "DRY RUN: launcher + gloo collectives only, no hot-path work, value is null",
-                       "parallelism": f"image-parallel x{world}", "batch_per_gpu": B}}), flush=True)
+                       "parallelism": f"image-parallel x{world}", "batch_per_gpu": B, "global_batch": B * world,
+                       "name": CONFIGS[args.config]["name"], "levels": len(CONFIGS[args.config]["shapes"])}}), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -465,7 +539,7 @@ def main():
     nstreams = int(os.environ.get("RDETR_BENCH_STREAMS", "2" if B % 2 == 0 and args.dtype == "bf16" else "1"))
     if nstreams < 1 or B % nstreams:
         raise SystemExit("RDETR_BENCH_STREAMS must divide --batch")
-    if args.dtype == "fp32" and nstreams > 1 and os.environ.get("RDETR_BENCH_FP32_GROUPS_UNSAFE") != "1":
+    if args.dtype == "fp32" and nstreams > 1:                # relation_detr_amd.graph.ImageGroups refuses it too
         raise SystemExit("[bench] fp32 runs as one image group (two fp32 groups side by side hang on this image, DESIGN.md 5)")
 
     def make_runner(queries, net_dtype, inputs, groups=None):
@@ -499,7 +573,7 @@ def main():
 
     # Set-up, not part of the contract's W + K steps: ~50 ms of replays so that the W warm-up steps and the K timed ones run at
     # sustained clocks (after the idle capture phase the first ~25 ms of any load run at ramping clocks, DESIGN.md 4.1 "Round 3").
-    for _ in range(12):
+    for _ in range(SETUP_REPLAYS):
         run(*flat_inputs)
     for _ in range(args.warmup):
         step()
@@ -526,9 +600,33 @@ def main():
         for _ in range(max(4, int(0.05 * args.steps / max(el, 1e-6)))):
             run(*flat_inputs)
 
-    t_kernel, S, L = time_encoder_kernel(B, dev, dtype, level_shapes=cfg["shapes"], busy=busy)
+    t_kernel_cold = time_encoder_kernel(B, dev, dtype, reps=20, level_shapes=cfg["shapes"], busy=None)[0]     # round-2 protocol: 3 warm-up + 20
+    t_kernel, S, L = time_encoder_kernel(B, dev, dtype, reps=KERNEL_REPS, level_shapes=cfg["shapes"], busy=busy)
     t_kernel_bshd = time_encoder_kernel(B, dev, dtype, layout="bshd", level_shapes=cfg["shapes"], busy=busy)[0] if args.dtype == "bf16" else None
     t_kernel_fp32 = time_encoder_kernel(B, dev, torch.float32, level_shapes=cfg["shapes"], busy=busy)[0] if args.dtype == "bf16" else None
+    in_stack = relation = sweep_ms = None
+    if args.dtype == "bf16" and rank == 0:
+        note("in-stack gather instantiation, relation kernels")
+        in_stack = {"kernel": "msda_fwd_qrun_kernel<bf16, L=%d, FUSED=true> on the head-major value (what the timed region launches for the "
+                              "encoder's MSDA: raw bf16 offsets / logits + fp32 reference points in, softmax and location arithmetic "
+                              "inside the kernel), encoder shape, isolated" % L}
+        for bb in sorted({B, max(1, B // max(1, nstreams))}, reverse=True):      # the whole batch, and one image group of it
+            t_f, moved, survey = time_in_stack_kernel(bb, dev, level_shapes=cfg["shapes"], busy=busy)
+            in_stack["B%d" % bb] = {"kernel_ms": t_f * 1e3, "bytes_moved": moved, "frac_of_bytes_moved": moved / t_f / HBM_PEAK,
+                                    "survey_8d_bytes": survey, "frac_of_survey_bytes": survey / t_f / HBM_PEAK}
+        t_bias, bias_bytes, t_attn = time_relation_kernels(B, dev, N=Nq, busy=busy)
+        relation = {"bias_materialised": {"kernel": "relation_bias_kernel via rdetr_relation_bias_ws_f32, B=%d, N=%d "
+                                                    "(relation_transformer.py:493-532)" % (B, Nq), "bound": "hbm (write)",
+                                          "kernel_ms": t_bias * 1e3, "algorithmic_bytes": bias_bytes,
+                                          "achieved": bias_bytes / t_bias / 1e9, "frac": bias_bytes / t_bias / HBM_PEAK},
+                    "attention_generating_the_bias": {"kernel": "relation_attention_boxes_kernel via rdetr_relation_attention_boxes_bf16, "
+                                                                "B=%d, N=%d (relation_transformer.py:452-461 with :493-532 inside)" % (B, Nq),
+                                                      "bound": "valu / transcendental (time only)", "kernel_ms": t_attn * 1e3}}
+        if args.config == "r50":
+            try:
+                sweep_ms = time_sweep_kernel(B, dev, level_shapes=cfg["shapes"], busy=busy) * 1e3
+            except RuntimeError as e:
+                print(f"[bench] sweep kernel skipped ({type(e).__name__}: {str(e)[:120]})", file=sys.stderr)
     note("side measurements")
     alg = msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 2 if args.dtype == "bf16" else 4)
 
@@ -633,7 +731,7 @@ def main():
         res = {
             "metric": cfg["metric"],
             "value": world * B * args.steps / el, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "setup_replays": SETUP_REPLAYS, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "value_300_queries": value_300, "value_gemm_tuned": value_tuned, "value_two_batches_in_flight": value_two_in_flight,
             "world_size_seen": dist.get_world_size() if use_dist else 1,
@@ -656,6 +754,18 @@ def main():
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / t_kernel / HBM_PEAK, **pmc_traffic(args.dtype, B, args.config),
                          "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3,
+                         "kernel_ms_cold": t_kernel_cold * 1e3, "frac_cold": alg / t_kernel_cold / HBM_PEAK,
+                         "kernel_timing": "kernel_ms: %d timed launches right after ~50 ms of the stack's own replays and %d untimed "
+                                          "launches, no host synchronisation in between (sustained clocks); kernel_ms_cold: 3 warm-up + "
+                                          "20 timed launches after a host synchronisation (round-2 protocol: measures the clock ramp)"
+                                          % (KERNEL_REPS, 2 * KERNEL_REPS),
+                         "kernel_preheat_launches": 2 * KERNEL_REPS,
+                         "in_stack": in_stack, "relation": relation,
+                         "lds_sourced_alternative": None if sweep_ms is None else {
+                             "kernel": "msda_fwd_sweep_kernel (csrc/msda_sweep.hip, opt-in algo='sweep'), same inputs", "kernel_ms": sweep_ms,
+                             "frac": alg / (sweep_ms * 1e-3) / HBM_PEAK,
+                             "data_path_ceiling": "tools/microbench/lds_gather_mfma_rate: 56 us for the ds_read_b64_tr_b16 + MFMA loop alone "
+                                                  "(0.51 of the roofline with nothing else), profiles/r04/"},
                          "fp32": None if t_kernel_fp32 is None else {
                              "kernel": "msda_fwd_qrun_kernel<float> on value [B,S,H,D] (the reference operator's own arithmetic, ms_deform_attn.py:360)",
                              "kernel_ms": t_kernel_fp32 * 1e3, "algorithmic_bytes": msda_algorithmic_bytes(B, S, S, L, 4, 8, 32, 4),

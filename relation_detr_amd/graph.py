@@ -39,6 +39,14 @@ class ImageGroups:
     def __call__(self, *tensors: torch.Tensor):
         if self.groups == 1:
             return self._fn(*tensors)
+        # fp32 activations: refused before anything is launched.  The dense projections of an fp32 stack run on the GEMM library,
+        # whose fp32 kernels on this image are all stream-K variants (`Cijk_..._SK3_SKXCCM8_...` in the one-stream trace,
+        # profiles/r01/bench_fullstack_fp32_kernel_stats.csv): persistent grids whose workgroups wait on partial tiles of their
+        # peers.  Two of them side by side on two streams stop making progress -- the device hangs (profiles/r03/
+        # fp32_two_group_hang_bisect.txt: `gemm_2streams`).  bf16 stacks use this package's own projection kernels.
+        if any(t.dtype == torch.float32 for t in tensors):
+            raise _lib.RdetrError("ImageGroups: float32 inputs run as ONE image group (two fp32 groups on parallel streams hang "
+                                  "the device: concurrent stream-K library GEMMs, DESIGN.md section 5); use groups=1 or bfloat16")
         B = tensors[0].shape[0]
         if B % self.groups or any(t.shape[0] != B for t in tensors):
             raise _lib.RdetrError(f"ImageGroups: every tensor needs the same batch size, divisible by {self.groups}")

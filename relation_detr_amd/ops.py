@@ -1086,11 +1086,17 @@ class _PackedWeightCache:
     source tensors and is only a hit while every reference still resolves to the very tensor passed in and the versions
     match.  A freed model whose storage address is recycled by the caching allocator for another model's weights (same
     `data_ptr()`, same `_version` after an identical build sequence) can therefore never alias a stale packed copy --
-    the pattern `host_levels` uses for the shape tables."""
+    the pattern `host_levels` uses for the shape tables.
+    Lifetime: a packed copy lives exactly as long as its source tensors.  The cache holds the ONLY reference to a copy whose
+    address a captured HIP graph may have baked in (relation_detr_amd/graph.py replays kernels that read it), so an entry is
+    never evicted while its sources are alive -- only entries whose sources are gone are pruned (every `prune_every` misses);
+    the dictionary simply grows with the number of live weight tensors (a size cap with `clear()` freed copies
+    that live graphs of a second network still read)."""
 
-    def __init__(self, limit: int = 64):
+    def __init__(self, prune_every: int = 64):
         self._entries: dict = {}
-        self._limit = limit
+        self._prune_every = prune_every
+        self._misses = 0
 
     def get(self, tensors, build):
         key = tuple(id(t) for t in tensors)
@@ -1100,10 +1106,9 @@ class _PackedWeightCache:
             refs, hver, packed = hit
             if hver == ver and all(r() is t for r, t in zip(refs, tensors)):
                 return packed
-        if len(self._entries) >= self._limit:           # drop entries whose tensors are gone, then (rarely) everything
+        self._misses += 1
+        if self._misses % self._prune_every == 0:       # drop the entries whose tensors are gone; live ones are never evicted
             self._entries = {k: v for k, v in self._entries.items() if all(r() is not None for r in v[0])}
-            if len(self._entries) >= self._limit:
-                self._entries.clear()
         packed = build()
         self._entries[key] = (tuple(weakref.ref(t) for t in tensors), ver, packed)
         return packed

@@ -84,6 +84,21 @@ def test_bench_launcher_two_ranks_dry_run():
     assert res["metric"].startswith("images/sec @ 800") and "300 queries" in res["metric"]
 
 
+def test_bench_launcher_two_ranks_dry_run_focalnet_config():
+    """BASELINE.json configs[4] through the same launcher path the driver will use on an 8-GPU node: `--config focalnet`
+    takes its per-rank batch (B = 2) and its metric string from the config table, the per-step gather carries
+    [2 x world, 300, 6] detections (util/utils.py:79-119, main.py:106-115 equivalents)."""
+    rc, lines, err = _run_bench(["--config", "focalnet", "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    res = lines[0]
+    assert res["n_gpus"] == 2 and res["world_size_seen"] == 2 and res["dry_run"] is True and res["gather_ok"] is True
+    assert res["metric"].startswith("images/sec @ 1200") and "FocalNet-L 5-level" in res["metric"]
+    cfg = res["config"]
+    assert cfg["batch_per_gpu"] == 2 and cfg["global_batch"] == 4 and cfg["levels"] == 5
+    assert cfg["name"] == "relation_detr_focalnet_large_lrf_fl4_1200_2000"
+
+
 def test_bench_launcher_ends_all_ranks_when_one_dies():
     """A rank that exits non-zero before its first collective must not leave the launcher waiting on the other rank's
     collective timeout (poll all children, end the rest on the first failure, return non-zero) -- and the

@@ -88,7 +88,12 @@ def test_fp32_stack_matches_cpu_oracle_full_size(bench, config, queries):
     # and the harness's own decoder outputs are the ones just checked (same proposals in, same kernels)
     # (the full forward takes its valid ratios / reference points from rdetr_pyramid_points, the re-run from the torch
     # statements: equal up to the last bit, which six layers turn into <= 1e-3 on logits of +-7 at 204k tokens)
-    np.testing.assert_allclose(got[0].float().cpu().numpy(), g_cls.float().cpu().numpy(), rtol=1e-4, atol=1e-3)
+    # -- the loose bound is the FocalNet case's only; r50: 1e-4 (measured 6.5e-5 at 900 queries: the same
+    # last-bit difference of the reference points through six layers at 22k tokens; 1e-5 does not hold there either)
+    if config == "focalnet":
+        np.testing.assert_allclose(got[0].float().cpu().numpy(), g_cls.float().cpu().numpy(), rtol=1e-4, atol=1e-3)
+    else:
+        np.testing.assert_allclose(got[0].float().cpu().numpy(), g_cls.float().cpu().numpy(), rtol=0, atol=1e-4)
 
 
 def test_bf16_two_group_replay_vs_fp32_full_size(bench):
@@ -165,8 +170,12 @@ def test_bf16_decoder_on_identical_proposals_full_size(bench):
     for l in range(L):
         w = masks[l].shape[2]
         masks[l][1, :, w * 150 // 168:] = True
-    net32 = bench.build_network(900, 0).to(DEV)
-    net16 = bench.build_network(900, 0).to(DEV).to(torch.bfloat16)
+    # DISTINCT content queries (the reference's N(0, 1) tgt_embed rows): with identical proposals handed to both decoders the
+    # slot-permutation argument for bench.py's exchangeable rows does not apply, and per-slot query handling (query_pos_k256,
+    # the stride-0 expand of layer 0) is only exercised by rows that differ
+    net32 = bench.build_network(900, 0, exchangeable_queries=False).to(DEV)
+    net16 = bench.build_network(900, 0, exchangeable_queries=False).to(DEV).to(torch.bfloat16)
+    assert (net32.tgt_embed.weight[0] - net32.tgt_embed.weight[1]).abs().max().item() > 0.1
     seen = {}
     net32.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("memory", o.detach().clone()))
     with torch.no_grad():

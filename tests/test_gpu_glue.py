@@ -88,15 +88,17 @@ def test_graph_replay_matches_eager(dtype):
 
 def test_image_groups_on_parallel_streams_match_one_stream():
     """ImageGroups: the batch as two image groups on two HIP streams -- eager and inside a captured graph -- gives every
-    image the result of the one-stream run (fp32: the per-image arithmetic does not depend on the group size except for
-    the library GEMMs' tiling, hence a tolerance instead of bit equality)."""
+    image the result of the one-stream run (bf16: the per-image arithmetic does not depend on the group size except for
+    the GEMM tiling of the few library projections, hence a tolerance instead of bit equality).  float32 inputs with more than
+    one group are REFUSED before anything is launched: two fp32 groups side by side hang the device (concurrent stream-K
+    library GEMMs, profiles/r03/fp32_two_group_hang_bisect.txt)."""
     from relation_detr_amd import _lib
     from relation_detr_amd.graph import GraphedCall, ImageGroups
     from relation_detr_amd.transformer import build_relation_transformer
     torch.manual_seed(0)
     shapes = [(40, 56), (20, 28), (10, 14), (5, 7)]
     net = build_relation_transformer(num_classes=17, d_ffn=128, enc_layers=2, dec_layers=2, num_queries=50,
-                                     hybrid_num_proposals=60).eval().to(DEV)
+                                     hybrid_num_proposals=60).eval().to(DEV).to(torch.bfloat16)
     with torch.no_grad():
         for m in net.modules():
             if hasattr(m, "sampling_offsets"):
@@ -104,8 +106,8 @@ def test_image_groups_on_parallel_streams_match_one_stream():
                 m.attention_weights.weight.normal_(0, 0.05)
     B, L = 4, len(shapes)
     g = torch.Generator().manual_seed(5)
-    feats = [torch.randn(B, 256, h, w, generator=g).to(DEV) for h, w in shapes]
-    pos = [torch.randn(B, 256, h, w, generator=g).to(DEV) for h, w in shapes]
+    feats = [torch.randn(B, 256, h, w, generator=g).to(DEV, torch.bfloat16) for h, w in shapes]
+    pos = [torch.randn(B, 256, h, w, generator=g).to(DEV, torch.bfloat16) for h, w in shapes]
     masks = []
     for h, w in shapes:
         m = torch.zeros(B, h, w, dtype=torch.bool)
@@ -113,11 +115,13 @@ def test_image_groups_on_parallel_streams_match_one_stream():
         m[3, int(h * 0.7):, :] = True
         masks.append(m.to(DEV))
     inputs = [*feats, *masks, *pos]
+    launched = []
 
     @torch.no_grad()
     def forward(*t):
+        launched.append(t[0].dtype)
         classes, coords = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))[:2]
-        return classes[-1], coords[-1]
+        return classes[-1].float(), coords[-1].float()
 
     want = [x.clone() for x in forward(*inputs)]
     two = ImageGroups(forward, 2, device=DEV)
@@ -126,10 +130,68 @@ def test_image_groups_on_parallel_streams_match_one_stream():
     torch.cuda.synchronize()
     for w_, g_, r_ in zip(want, got, replay):
         assert g_.shape == w_.shape
-        assert torch.allclose(g_, w_, atol=2e-4, rtol=1e-4)
-        assert torch.allclose(r_, w_, atol=2e-4, rtol=1e-4)
+        scale = w_.abs().max().item()
+        assert (g_ - w_).abs().max().item() <= 2.0 ** -5 * scale
+        assert (r_ - w_).abs().max().item() <= 2.0 ** -5 * scale
     with pytest.raises(_lib.RdetrError):
         ImageGroups(forward, 3, device=DEV)(*inputs)
+    # fp32 + two groups: refused, nothing launched
+    launched.clear()
+    fp32_inputs = [t.float() if t.is_floating_point() else t for t in inputs]
+    with pytest.raises(_lib.RdetrError, match="float32"):
+        two(*fp32_inputs)
+    assert launched == []
+    assert ImageGroups(lambda *t: t[0] * 2, 1, device=DEV)(fp32_inputs[0]).dtype == torch.float32        # one group: fine
+
+
+def test_two_graphed_networks_replayed_alternately_match_eager():
+    """Two bf16 networks, each captured into its own hipGraph, replayed alternately: every replay returns the bits of the eager
+    run.  The packed (fragment-order) weight copies the captured kernels read are owned by ops._PackedWeightCache and live as
+    long as their source weights -- a size-capped cache used to free the first network's copies when the second one was built
+    (ADVICE round 3, high)."""
+    from relation_detr_amd import ops
+    from relation_detr_amd.graph import GraphedCall
+    from relation_detr_amd.transformer import build_relation_transformer, select_detections
+    shapes = [(40, 56), (20, 28), (10, 14), (5, 7)]
+    B, L = 2, len(shapes)
+    nets = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        net = build_relation_transformer(num_classes=17, d_ffn=256, enc_layers=6, dec_layers=6, num_queries=50,
+                                         hybrid_num_proposals=60).eval().to(DEV).to(torch.bfloat16)
+        with torch.no_grad():
+            for m in net.modules():
+                if hasattr(m, "sampling_offsets"):
+                    m.sampling_offsets.weight.normal_(0, 0.02)
+                    m.attention_weights.weight.normal_(0, 0.05)
+        nets.append(net)
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        feats = [torch.randn(B, 256, h, w, generator=g).to(DEV, torch.bfloat16) for h, w in shapes]
+        pos = [torch.randn(B, 256, h, w, generator=g).to(DEV, torch.bfloat16) for h, w in shapes]
+        masks = [torch.zeros(B, h, w, dtype=torch.bool, device=DEV) for h, w in shapes]
+        return [*feats, *masks, *pos, torch.tensor([[400, 560], [400, 448]], device=DEV)]
+
+    def forward_of(net):
+        @torch.no_grad()
+        def forward(*t):
+            classes, coords = net(list(t[:L]), list(t[L:2 * L]), list(t[2 * L:3 * L]))[:2]
+            return select_detections(classes[-1].float(), coords[-1].float(), t[3 * L], k=20)
+        return forward
+
+    fwd = [forward_of(n) for n in nets]
+    a, b = make(1), make(2)
+    eager = [[f(*inp).clone() for inp in (a, b)] for f in fwd]
+    # (each graph owns its static input buffers: a replay with other tensors copies them in)
+    runs = [GraphedCall(fwd[0], [t.clone() for t in a]), GraphedCall(fwd[1], [t.clone() for t in a])]   # building the second must
+                                                                                                      # not free the first one's copies
+    assert len(ops._LINEAR_PACKED) + len(ops._FFN_PACKED) >= 2 * 12     # both networks' packed weights are alive in the caches
+    for rnd in range(3):
+        for i, inp in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            out = runs[i](*(a, b)[inp]).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager[i][inp]), (rnd, i, inp)
 
 
 # ------------------------------------------------------------------------------------------ fused decoder self-attention

@@ -151,7 +151,7 @@ def test_packed_weight_cache_is_tied_to_tensor_objects():
     import torch
 
     from relation_detr_amd.ops import _PackedWeightCache
-    cache, builds = _PackedWeightCache(limit=4), []
+    cache, builds = _PackedWeightCache(prune_every=4), []
 
     def build_for(t):
         def build():
@@ -171,12 +171,25 @@ def test_packed_weight_cache_is_tied_to_tensor_objects():
     cache._entries[(id(b),)] = stale                                           # same "version", wrong object behind the weakref
     p3 = cache.get((b,), build_for(b))
     assert torch.equal(p3, b * 2) and len(builds) == 3
-    del a
-    gc.collect()
-    for i in range(6):                                                         # eviction keeps live entries consistent
-        t = torch.full((2, 2), float(i))
+    # lifetime: the packed copy of a LIVE tensor is never evicted, however many other weights pass through --
+    # a captured HIP graph may read it on replay and the cache holds the only reference
+    keep = [torch.full((2, 2), float(i)) for i in range(40)]
+    packed_b = cache.get((b,), build_for(b))
+    for t in keep:
         assert torch.equal(cache.get((t,), build_for(t)), t * 2)
-    assert len(cache) <= 5
+    assert cache.get((b,), build_for(b)) is packed_b and len(cache) >= 41
+    for t in keep:
+        assert cache.get((t,), build_for(t)) is cache.get((t,), build_for(t))
+    # ... and entries of dead tensors are pruned
+    n_live = len(cache)
+    del keep, t
+    gc.collect()
+    for i in range(8):
+        u = torch.full((3, 3), float(i))
+        cache.get((u,), build_for(u))
+        del u
+    gc.collect()
+    assert len(cache) < n_live
 
 
 def test_levels_window_ok_host_helper():

@@ -50,6 +50,17 @@ struct LevelTable {
 
 template <typename T> struct ValueIO;
 
+// Query-side streams (sampling locations / weights or raw offsets / logits, reference points) and the output rows are touched
+// ONCE per launch, the value rows dozens of times.  RDETR_NT_STREAMS (development A/B): mark the streams
+// non-temporal so that they do not push value rows out of the XCD's 4-MiB L2.
+#ifdef RDETR_NT_STREAMS
+template <typename V> __device__ __forceinline__ V qload(const V *p) { return __builtin_nontemporal_load(p); }
+template <typename V> __device__ __forceinline__ void qstore(V *p, V v) { __builtin_nontemporal_store(v, p); }
+#else
+template <typename V> __device__ __forceinline__ V qload(const V *p) { return *p; }
+template <typename V> __device__ __forceinline__ void qstore(V *p, V v) { *p = v; }
+#endif
+
 template <> struct ValueIO<float> {
     static constexpr int kRunSub = 8, kRunCh = 4;                    // 8 lanes x 4 channels (16 B) per 128-byte head row
     static constexpr unsigned kHeadBytes = kHeadDim * 4;             // 128 B: one cache line per head row
@@ -61,7 +72,7 @@ template <> struct ValueIO<float> {
     }
     static __device__ __forceinline__ void store_run(float *p, const float (&a)[4])
     {
-        *reinterpret_cast<f32x4 *>(p) = f32x4{a[0], a[1], a[2], a[3]};
+        qstore(reinterpret_cast<f32x4 *>(p), f32x4{a[0], a[1], a[2], a[3]});
     }
 };
 
@@ -84,20 +95,20 @@ template <> struct ValueIO<uint16_t> {                               // bf16 sto
         o.y = f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16);
         o.z = f32_to_bf16_bits(a[4]) | (f32_to_bf16_bits(a[5]) << 16);
         o.w = f32_to_bf16_bits(a[6]) | (f32_to_bf16_bits(a[7]) << 16);
-        *reinterpret_cast<u32x4 *>(p) = o;
+        qstore(reinterpret_cast<u32x4 *>(p), o);
     }
 };
 
 // Query-side scalar loads: the producer inputs (sampling offsets / attention logits) arrive in the
 // dtype of the projection that made them: fp32, or bf16 under autocast.
 template <typename Q> __device__ __forceinline__ float load_q(const Q *p);
-template <> __device__ __forceinline__ float load_q<float>(const float *p) { return *p; }
-template <> __device__ __forceinline__ float load_q<uint16_t>(const uint16_t *p) { return bf16_bits_to_f32(*p); }
+template <> __device__ __forceinline__ float load_q<float>(const float *p) { return qload(p); }
+template <> __device__ __forceinline__ float load_q<uint16_t>(const uint16_t *p) { return bf16_bits_to_f32(qload(p)); }
 template <typename Q> __device__ __forceinline__ f32x2 load_q2(const Q *p);
-template <> __device__ __forceinline__ f32x2 load_q2<float>(const float *p) { return *reinterpret_cast<const f32x2 *>(p); }
+template <> __device__ __forceinline__ f32x2 load_q2<float>(const float *p) { return qload(reinterpret_cast<const f32x2 *>(p)); }
 template <> __device__ __forceinline__ f32x2 load_q2<uint16_t>(const uint16_t *p)
 {
-    const unsigned u = *reinterpret_cast<const unsigned *>(p);
+    const unsigned u = qload(reinterpret_cast<const unsigned *>(p));
     return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 }
 
@@ -119,28 +130,28 @@ template <typename Q, int N> struct LoadQ;
 template <> struct LoadQ<float, 2> {
     static __device__ __forceinline__ void run(const float *p, float (&v)[2])
     {
-        const f32x2 r = *reinterpret_cast<const f32x2 *>(p);
+        const f32x2 r = qload(reinterpret_cast<const f32x2 *>(p));
         v[0] = r.x; v[1] = r.y;
     }
 };
 template <> struct LoadQ<float, 4> {
     static __device__ __forceinline__ void run(const float *p, float (&v)[4])
     {
-        const f32x4 r = *reinterpret_cast<const f32x4 *>(p);
+        const f32x4 r = qload(reinterpret_cast<const f32x4 *>(p));
         v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
     }
 };
 template <> struct LoadQ<float, 8> {
     static __device__ __forceinline__ void run(const float *p, float (&v)[8])
     {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+        const f32x4 a = qload(reinterpret_cast<const f32x4 *>(p)), b = qload(reinterpret_cast<const f32x4 *>(p + 4));
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
 };
 template <> struct LoadQ<uint16_t, 4> {
     static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[4])
     {
-        const u32x2 r = *reinterpret_cast<const u32x2 *>(p);
+        const u32x2 r = qload(reinterpret_cast<const u32x2 *>(p));
         v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
         v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
     }
@@ -148,7 +159,7 @@ template <> struct LoadQ<uint16_t, 4> {
 template <> struct LoadQ<uint16_t, 8> {
     static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[8])
     {
-        const u32x4 r = *reinterpret_cast<const u32x4 *>(p);
+        const u32x4 r = qload(reinterpret_cast<const u32x4 *>(p));
         v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
         v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
         v[4] = __builtin_bit_cast(float, r.z << 16); v[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
@@ -162,7 +173,14 @@ template <> struct LoadQ<uint16_t, 10> {
     static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[10])
     {
         unsigned r[5];
+#ifdef RDETR_NT_STREAMS
+        typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+        const u32x4 q4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(p));
+        r[0] = q4.x; r[1] = q4.y; r[2] = q4.z; r[3] = q4.w;
+        r[4] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p) + 4);
+#else
         __builtin_memcpy(r, __builtin_assume_aligned(p, 4), 20);
+#endif
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             v[2 * i] = __builtin_bit_cast(float, r[i] << 16);
@@ -174,7 +192,12 @@ template <> struct LoadQ<uint16_t, 5> {
     static __device__ __forceinline__ void run(const uint16_t *p, float (&v)[5])
     {
         uint16_t r[5];
+#ifdef RDETR_NT_STREAMS
+#pragma unroll
+        for (int i = 0; i < 5; ++i) r[i] = __builtin_nontemporal_load(p + i);
+#else
         __builtin_memcpy(r, __builtin_assume_aligned(p, 2), 10);
+#endif
 #pragma unroll
         for (int i = 0; i < 5; ++i) v[i] = bf16_bits_to_f32(r[i]);
     }
@@ -182,13 +205,28 @@ template <> struct LoadQ<uint16_t, 5> {
 template <> struct LoadQ<float, 10> {
     static __device__ __forceinline__ void run(const float *p, float (&v)[10])
     {
+#ifdef RDETR_NT_STREAMS
+        typedef f32x4 __attribute__((aligned(8))) f32x4_a8;
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_a8 *>(p));
+        const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_a8 *>(p + 4));
+        const f32x2 c = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p + 8));
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = c.x; v[9] = c.y;
+#else
         __builtin_memcpy(v, __builtin_assume_aligned(p, 8), 40);
+#endif
     }
 };
 template <> struct LoadQ<float, 5> {
     static __device__ __forceinline__ void run(const float *p, float (&v)[5])
     {
+#ifdef RDETR_NT_STREAMS
+        typedef f32x4 __attribute__((aligned(4))) f32x4_a4;
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_a4 *>(p));
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = __builtin_nontemporal_load(p + 4);
+#else
         __builtin_memcpy(v, __builtin_assume_aligned(p, 4), 20);
+#endif
     }
 };
 
@@ -236,7 +274,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
     int L_rt, int Nq, int tiles_per_image, int nblk, T *__restrict__ out,
-    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major, int value_pix_bytes)
+    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major, int value_pix_bytes, int interleave)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
@@ -297,8 +335,52 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     // logical block -> (image b, head m, tile of consecutive queries); tiles of one (b, m) are consecutive
     const int logical = xcd_contiguous_block(blockIdx.x, nblk);
     const int bm = logical / tiles_per_image;
-    const int tile = logical - bm * tiles_per_image;
+    int tile = logical - bm * tiles_per_image;
     const int b = bm / kHeads, m = bm - b * kHeads;
+    // Encoder shape (queries = the pyramid's pixels, `interleave`): the tiles of one (image, head) are taken in BANDS -- ~16-31
+    // tiles of level 0 followed by the proportional share of every coarser level's tiles -- instead of level after level.  In
+    // query order every level's queries sweep the WHOLE value plane once more (5 sweeps of 13 MB per plane at the FocalNet
+    // size, where an XCD's L2 holds 4 MiB: 2.2 GB leave the L2s for 0.99 GB of distinct bytes, profiles/r04/
+    // pmc_ea_sizes_direct_kernel.txt); interleaved, the queries of all levels over one part of the image run together and share
+    // its rows.  A pure re-ordering of the blocks (a bijection on the tiles for any level table; identity unless the level
+    // starts are non-decreasing): results are bit-identical.
+    if constexpr (LT != 0) {
+        if (interleave) {
+            constexpr int kQpb = kWavesPerBlock * kSlots;
+            int A[LT + 1];
+            bool mono = true;
+            A[0] = 0;
+#pragma unroll
+            for (int l = 1; l < LT; ++l) {
+                const int t = ((int)level_start[l] + kQpb - 1) / kQpb;
+                A[l] = t < tiles_per_image ? t : tiles_per_image;
+                mono = mono && A[l] >= A[l - 1];
+            }
+            A[LT] = tiles_per_image;
+            const int T0 = A[1] - A[0];
+            if (mono && T0 >= 64) {
+                const int k = 27 - __builtin_clz((unsigned)T0);                  // 2^k bands of 16..31 level-0 tiles
+                const int NB = 1 << k;
+                auto prefix = [&](int bnd) {
+                    int sum = 0;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) sum += (bnd * (A[l + 1] - A[l])) >> k;
+                    return sum;
+                };
+                int bnd = (int)((float)tile * (float)NB / (float)tiles_per_image);
+                bnd = bnd < 0 ? 0 : (bnd > NB - 1 ? NB - 1 : bnd);
+                while (bnd + 1 < NB && prefix(bnd + 1) <= tile) ++bnd;
+                while (bnd > 0 && prefix(bnd) > tile) --bnd;
+                int r = tile - prefix(bnd);
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    const int Tl = A[l + 1] - A[l], lo = (bnd * Tl) >> k, c = (((bnd + 1) * Tl) >> k) - lo;
+                    if (r >= 0 && r < c) tile = A[l] + lo + r;
+                    r = r >= 0 && r < c ? -1 : r - c;
+                }
+            }
+        }
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int qs = lane / kSub, sub = lane % kSub;
@@ -422,8 +504,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
             for (int k = 0; k < kPtsPerLane; ++k) {
                 const int pt = point_of(k);
                 const bool ok = pt < LP;
-                pxy[k] = ok ? *reinterpret_cast<const f32x2 *>(loc_q + 2 * pt) : f32x2{0.f, 0.f};
-                pa[k] = ok ? att_q[pt] : 0.f;
+                pxy[k] = ok ? qload(reinterpret_cast<const f32x2 *>(loc_q + 2 * pt)) : f32x2{0.f, 0.f};
+                pa[k] = ok ? qload(att_q + pt) : 0.f;
             }
         }
     }
@@ -587,12 +669,26 @@ int msda_win_forward(const uint16_t *value, const int64_t *shapes, const int64_t
                      const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, int ld_a, int ld_b,
                      uint16_t *out, hipStream_t stream);
 
+// development A/B of the block order (make dev: rdetr_dev_set_msda_identity_order); the product library always interleaves
+struct MsdaOrder {
+#ifdef RDETR_DEV
+    static inline bool identity = false;
+#else
+    static constexpr bool identity = false;
+#endif
+};
+
 template <typename T, bool FUSED>
 static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *value, const int64_t *shapes,
                         const int64_t *level_start, const void *src_a, const void *src_b, const float *ref, int ref_dim,
                         int S, int L, int Nq, int tiles, int nblk, T *out, const unsigned char *pad_mask, int ld_a, int ld_b,
                         int head_major, int value_pix_bytes)
 {
+    // encoder shape with an (image, head) value plane that does not fit an XCD's 4-MiB L2: band-interleaved block order.
+    // Same-box A/B (profiles/r04/ab_block_order_direct_kernel.txt): FocalNet-L 1200 x 2000 (13-MB planes) 872 -> 840 us and
+    // 2.19 -> 1.71 GB of L2 -> fabric reads; R50 800 x 1333 (1.4-MB planes, they stay in the L2 between the sweeps) 109 -> 113 us:
+    // there the query order keeps the better L1 locality.
+    const int interleave = (Nq == S && (long long)S * (long long)(kHeadDim * sizeof(T)) > (4ll << 20) && !MsdaOrder::identity) ? 1 : 0;
     // the 4-level kernel reads a lane's share of the query-side inputs as 16-byte vectors
     const bool vec_ok = reinterpret_cast<uintptr_t>(src_a) % 16 == 0 && reinterpret_cast<uintptr_t>(src_b) % 16 == 0 &&
                         (!FUSED || (reinterpret_cast<uintptr_t>(ref) % 16 == 0 && (ld_a * (int)sizeof(T)) % 16 == 0 &&
@@ -603,13 +699,13 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
                           (!FUSED || (reinterpret_cast<uintptr_t>(ref) % 16 == 0 && (ld_a * (int)sizeof(T)) % 4 == 0)));
     if (L == 4 && vec_ok)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, interleave);
     else if (L == 5 && vec5_ok)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, interleave);
     else
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, interleave);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
@@ -847,3 +943,7 @@ extern "C" int rdetr_value_to_head_major_bf16(const uint16_t *src, long long ld,
                        static_cast<hipStream_t>(stream), src, ld, key_padding_mask, S, dst);
     return rdetr::launch_status();
 }
+
+#ifdef RDETR_DEV
+extern "C" void rdetr_dev_set_msda_identity_order(int v) { rdetr::MsdaOrder::identity = v != 0; }
+#endif

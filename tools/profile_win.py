@@ -19,6 +19,10 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     algo = sys.argv[3] if len(sys.argv) > 3 else "window"
     dev = torch.device("cuda", 0)
+    if os.environ.get("RDETR_DEV_IDENTITY_ORDER") == "1":                  # development library only: blocks in query order
+        import ctypes
+        from relation_detr_amd import _lib
+        ctypes.CDLL(_lib.LIB_PATH).rdetr_dev_set_msda_identity_order(1)
     cfg = bench.CONFIGS[sys.argv[4]] if len(sys.argv) > 4 else bench.CONFIGS["r50"]          # [config]: r50 (B = 4) | focalnet (B = 2)
     value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(cfg["batch"], dev, torch.bfloat16, cfg["shapes"])
     v = value.permute(0, 2, 1, 3).contiguous() if lay == "bhsd" else value

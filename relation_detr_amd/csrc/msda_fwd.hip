@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const void *__restrict__ src_a, const void *__restrict__ src_b, const float *__restrict__ ref, int ref_dim, int S,
     int L_rt, int Nq, int tiles_per_image, int nblk, T *__restrict__ out,
-    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major, int value_pix_bytes, int interleave)
+    const unsigned char *__restrict__ pad_mask, int ld_a, int ld_b, int head_major, int value_pix_bytes, int order)
 {
     using IO = ValueIO<T>;
     constexpr int kSub = IO::kRunSub;            // lanes per head row
@@ -332,11 +332,16 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     auto level_w = [&](int l, int k) { return kConsec ? (second_level(k) ? my_w1 : my_w) : lvl.w[l]; };
     auto level_start_of = [&](int l, int k) { return kConsec ? (second_level(k) ? my_start1 : my_start) : lvl.start[l]; };
 
-    // logical block -> (image b, head m, tile of consecutive queries); tiles of one (b, m) are consecutive
+    // logical block -> (image b, head m, tile of consecutive queries).  `order` bit 0: band-interleaved tiles (below); bits 1-2 =
+    // log2 G of the HEAD GROUP: the G heads of a group take turns over the same tile (consecutive logical blocks = consecutive
+    // dispatches on one XCD), the tiles of one (image, head group) are consecutive.  The query-side rows hold a query's 8 heads
+    // side by side -- per head 128 B of locations + 64 B of weights at L = 4 (160 + 80 at L = 5; 64 + 32 B of raw offsets / logits
+    // in the FUSED form) -- so with one head per XCD every L2 fetches the 128-byte lines of its neighbours' heads as well
+    // (measured: 250 MB read for 183 MB distinct at R50, 1.71 GB for 0.99 GB at FocalNet); a group's heads share those lines in
+    // ONE L2, at the price of G value planes' rows competing for it.
     const int logical = xcd_contiguous_block(blockIdx.x, nblk);
-    const int bm = logical / tiles_per_image;
-    int tile = logical - bm * tiles_per_image;
-    const int b = bm / kHeads, m = bm - b * kHeads;
+    const int hg = (order >> 1) & 3, interleave = order & 1;
+    static_assert(kHeads == 8, "head-group decode assumes 8 heads");
     // Encoder shape (queries = the pyramid's pixels, `interleave`): the tiles of one (image, head) are taken in BANDS -- ~16-31
     // tiles of level 0 followed by the proportional share of every coarser level's tiles -- instead of level after level.  In
     // query order every level's queries sweep the WHOLE value plane once more (5 sweeps of 13 MB per plane at the FocalNet
@@ -344,43 +349,53 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void msda_fwd_qrun_kernel(
     // pmc_ea_sizes_direct_kernel.txt); interleaved, the queries of all levels over one part of the image run together and share
     // its rows.  A pure re-ordering of the blocks (a bijection on the tiles for any level table; identity unless the level
     // starts are non-decreasing): results are bit-identical.
-    if constexpr (LT != 0) {
-        if (interleave) {
-            constexpr int kQpb = kWavesPerBlock * kSlots;
-            int A[LT + 1];
-            bool mono = true;
-            A[0] = 0;
+    auto decode = [&](int lg, int &b_, int &m_, int &tile_) {
+        const int per_group = tiles_per_image << hg;
+        const int grp = lg / per_group, r_in = lg - grp * per_group;
+        int tile = r_in >> hg;
+        b_ = grp >> (3 - hg);
+        m_ = ((grp & ((kHeads >> hg) - 1)) << hg) | (r_in & ((1 << hg) - 1));
+        if constexpr (LT != 0) {
+            if (interleave) {
+                constexpr int kQpb = kWavesPerBlock * kSlots;
+                int A[LT + 1];
+                bool mono = true;
+                A[0] = 0;
 #pragma unroll
-            for (int l = 1; l < LT; ++l) {
-                const int t = ((int)level_start[l] + kQpb - 1) / kQpb;
-                A[l] = t < tiles_per_image ? t : tiles_per_image;
-                mono = mono && A[l] >= A[l - 1];
-            }
-            A[LT] = tiles_per_image;
-            const int T0 = A[1] - A[0];
-            if (mono && T0 >= 64) {
-                const int k = 27 - __builtin_clz((unsigned)T0);                  // 2^k bands of 16..31 level-0 tiles
-                const int NB = 1 << k;
-                auto prefix = [&](int bnd) {
-                    int sum = 0;
+                for (int l = 1; l < LT; ++l) {
+                    const int t = ((int)level_start[l] + kQpb - 1) / kQpb;
+                    A[l] = t < tiles_per_image ? t : tiles_per_image;
+                    mono = mono && A[l] >= A[l - 1];
+                }
+                A[LT] = tiles_per_image;
+                const int T0 = A[1] - A[0];
+                if (mono && T0 >= 64) {
+                    const int k = 27 - __builtin_clz((unsigned)T0);                  // 2^k bands of 16..31 level-0 tiles
+                    const int NB = 1 << k;
+                    auto prefix = [&](int bnd) {
+                        int sum = 0;
 #pragma unroll
-                    for (int l = 0; l < LT; ++l) sum += (bnd * (A[l + 1] - A[l])) >> k;
-                    return sum;
-                };
-                int bnd = (int)((float)tile * (float)NB / (float)tiles_per_image);
-                bnd = bnd < 0 ? 0 : (bnd > NB - 1 ? NB - 1 : bnd);
-                while (bnd + 1 < NB && prefix(bnd + 1) <= tile) ++bnd;
-                while (bnd > 0 && prefix(bnd) > tile) --bnd;
-                int r = tile - prefix(bnd);
+                        for (int l = 0; l < LT; ++l) sum += (bnd * (A[l + 1] - A[l])) >> k;
+                        return sum;
+                    };
+                    int bnd = (int)((float)tile * (float)NB / (float)tiles_per_image);
+                    bnd = bnd < 0 ? 0 : (bnd > NB - 1 ? NB - 1 : bnd);
+                    while (bnd + 1 < NB && prefix(bnd + 1) <= tile) ++bnd;
+                    while (bnd > 0 && prefix(bnd) > tile) --bnd;
+                    int r = tile - prefix(bnd);
 #pragma unroll
-                for (int l = 0; l < LT; ++l) {
-                    const int Tl = A[l + 1] - A[l], lo = (bnd * Tl) >> k, c = (((bnd + 1) * Tl) >> k) - lo;
-                    if (r >= 0 && r < c) tile = A[l] + lo + r;
-                    r = r >= 0 && r < c ? -1 : r - c;
+                    for (int l = 0; l < LT; ++l) {
+                        const int Tl = A[l + 1] - A[l], lo = (bnd * Tl) >> k, c = (((bnd + 1) * Tl) >> k) - lo;
+                        if (r >= 0 && r < c) tile = A[l] + lo + r;
+                        r = r >= 0 && r < c ? -1 : r - c;
+                    }
                 }
             }
         }
-    }
+        tile_ = tile;
+    };
+    int b, m, tile;
+    decode(logical, b, m, tile);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int qs = lane / kSub, sub = lane % kSub;
@@ -673,8 +688,10 @@ int msda_win_forward(const uint16_t *value, const int64_t *shapes, const int64_t
 struct MsdaOrder {
 #ifdef RDETR_DEV
     static inline bool identity = false;
+    static inline int head_group_log2 = -1;          // -1 = the product's choice
 #else
     static constexpr bool identity = false;
+    static constexpr int head_group_log2 = -1;
 #endif
 };
 
@@ -689,6 +706,12 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
     // 2.19 -> 1.71 GB of L2 -> fabric reads; R50 800 x 1333 (1.4-MB planes, they stay in the L2 between the sweeps) 109 -> 113 us:
     // there the query order keeps the better L1 locality.
     const int interleave = (Nq == S && (long long)S * (long long)(kHeadDim * sizeof(T)) > (4ll << 20) && !MsdaOrder::identity) ? 1 : 0;
+    // head pairs: same-box A/B over G = 1, 2, 4, 8 (profiles/r04/ab_head_group_direct_kernel.txt): FocalNet-L operator form 838 ->
+    // 805 us and 13.4 M -> 11.1 M read requests with G = 2 (G = 4: 823 us, 17.7 M -- four planes' rows no longer fit; G = 8: 862 us,
+    // 39 M), fused form 787 -> 747 us; [B,S,H,D] value (a pair's rows = one 128-byte line) 1179 -> 1014 us, at R50 127 -> 122 us;
+    // R50 head-major: equal within the boxes' clock noise, 1.95 M -> 1.82 M requests
+    const int hg = MsdaOrder::head_group_log2 >= 0 ? MsdaOrder::head_group_log2 : 1;
+    const int order = interleave | (hg << 1);
     // the 4-level kernel reads a lane's share of the query-side inputs as 16-byte vectors
     const bool vec_ok = reinterpret_cast<uintptr_t>(src_a) % 16 == 0 && reinterpret_cast<uintptr_t>(src_b) % 16 == 0 &&
                         (!FUSED || (reinterpret_cast<uintptr_t>(ref) % 16 == 0 && (ld_a * (int)sizeof(T)) % 16 == 0 &&
@@ -699,13 +722,13 @@ static void launch_qrun(dim3 grid, dim3 block, hipStream_t stream, const T *valu
                           (!FUSED || (reinterpret_cast<uintptr_t>(ref) % 16 == 0 && (ld_a * (int)sizeof(T)) % 4 == 0)));
     if (L == 4 && vec_ok)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 4, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, interleave);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, order);
     else if (L == 5 && vec5_ok)
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 5, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, interleave);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, order);
     else
         hipLaunchKernelGGL((msda_fwd_qrun_kernel<T, 0, FUSED>), grid, block, 0, stream, value, shapes, level_start, src_a,
-                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, interleave);
+                           src_b, ref, ref_dim, S, L, Nq, tiles, nblk, out, pad_mask, ld_a, ld_b, head_major, value_pix_bytes, order);
 }
 
 // FUSED = false: src_a / src_b = sampling locations / soft-maxed weights (fp32).
@@ -946,4 +969,5 @@ extern "C" int rdetr_value_to_head_major_bf16(const uint16_t *src, long long ld,
 
 #ifdef RDETR_DEV
 extern "C" void rdetr_dev_set_msda_identity_order(int v) { rdetr::MsdaOrder::identity = v != 0; }
+extern "C" void rdetr_dev_set_msda_head_group_log2(int v) { rdetr::MsdaOrder::head_group_log2 = v > 3 ? 3 : v; }
 #endif

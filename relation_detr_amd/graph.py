@@ -46,7 +46,7 @@ class ImageGroups:
         # fp32_two_group_hang_bisect.txt: `gemm_2streams`).  bf16 stacks use this package's own projection kernels.
         if any(t.dtype == torch.float32 for t in tensors):
             raise _lib.RdetrError("ImageGroups: float32 inputs run as ONE image group (two fp32 groups on parallel streams hang "
-                                  "the device: concurrent stream-K library GEMMs, DESIGN.md section 5); use groups=1 or bfloat16")
+                                  "the device: concurrent stream-K library GEMMs, DESIGN.md section 4.8); use groups=1 or bfloat16")
         B = tensors[0].shape[0]
         if B % self.groups or any(t.shape[0] != B for t in tensors):
             raise _lib.RdetrError(f"ImageGroups: every tensor needs the same batch size, divisible by {self.groups}")

@@ -23,6 +23,10 @@ def main():
         import ctypes
         from relation_detr_amd import _lib
         ctypes.CDLL(_lib.LIB_PATH).rdetr_dev_set_msda_identity_order(1)
+    if os.environ.get("RDETR_DEV_HEAD_GROUP_LOG2"):                         # development library only: heads per XCD-local group
+        import ctypes
+        from relation_detr_amd import _lib
+        ctypes.CDLL(_lib.LIB_PATH).rdetr_dev_set_msda_head_group_log2(int(os.environ["RDETR_DEV_HEAD_GROUP_LOG2"]))
     cfg = bench.CONFIGS[sys.argv[4]] if len(sys.argv) > 4 else bench.CONFIGS["r50"]          # [config]: r50 (B = 4) | focalnet (B = 2)
     value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(cfg["batch"], dev, torch.bfloat16, cfg["shapes"])
     v = value.permute(0, 2, 1, 3).contiguous() if lay == "bhsd" else value

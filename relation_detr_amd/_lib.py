@@ -28,6 +28,8 @@ SIGNATURES = {
     "rdetr_msda_forward_fused_ex_bf16": [_vp] * 4 + [_c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_opt_bf16": [_vp, _c_int] + [_vp] * 4 + [_c_int] * 8 + [_vp, _vp],
     "rdetr_msda_forward_sweep_bf16": [_vp, _c_int] + [_vp] * 4 + [_c_int] * 7 + [_vp, _vp],
+    "rdetr_msda_forward_resident_bf16": [_vp] * 5 + [_c_int] * 7 + [_vp, _vp],
+    "rdetr_msda_forward_fused_resident_bf16": [_vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_msda_forward_fused_opt_bf16": [_vp, _c_int, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 8 + [_vp, _vp],
     "rdetr_msda_forward_fused_strided_bf16": [_vp, _c_ll, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp] + [_c_int] * 7 + [_vp, _vp],
     "rdetr_value_to_head_major_bf16": [_vp, _c_ll, _vp] + [_c_int] * 4 + [_vp, _vp],
@@ -69,6 +71,8 @@ SIGNATURES = {
     "rdetr_add_layernorm_pos_f32": [_vp] * 5 + [_c_ll, _c_int] + [_c_ll] * 5 + [_c_float, _vp, _vp, _vp],
     "rdetr_add_layernorm_pos_bf16": [_vp] * 5 + [_c_ll, _c_int] + [_c_ll] * 5 + [_c_float, _vp, _vp, _vp],
 }
+
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = -1, -2, -3            # rdetr_status (include/relation_detr_amd.h)
 
 _lib = None
 

@@ -1,0 +1,452 @@
+// Multi-scale deformable attention, forward, bf16, head-major value [B,H,S,D] -- "resident coarse levels" kernel for gfx950.
+//
+// Same operator as msda_fwd.hip (reference: ms_deform_im2col_cuda.cuh:226-288) and the same per-query arithmetic in the same
+// order, so the results are bit-identical to msda_fwd_qrun_kernel's.  What changes is WHERE the corner rows come from.
+//
+// The query-run kernel brings every corner row through the texture path, whose addresser retires one 64-lane x 16-byte
+// instruction per ~16.5 clocks and CU: 64 such gathers per wave and run of 16 queries at 4 levels -- the kernel's ceiling
+// (DESIGN 4.1).  But the levels are not alike: at the R50 encoder shape levels 2 and 3 together are 1,323 pixels = 85 KB of
+// an (image, head) plane and receive HALF of all samples.  So:
+//   * one persistent 16-wave workgroup per CU serves ONE (image, head) plane (several, one after the other, when there are more
+//     planes than the XCD has workgroups) and keeps that plane's coarse levels lr .. L-1 -- as many as fit beside the staging
+//     area -- RESIDENT in LDS: one contiguous copy, since the levels are packed along S;
+//   * a sample on a resident level reads its corner rows with ds_read_b128 from that copy (a corner outside the level reads a
+//     64-byte row of zeros at LDS offset 0: the zero padding of .cuh:44-67), a sample on a fine level goes through the buffer
+//     descriptor as before.  No windows, no halo, no flagged samples: a resident level is resident as a whole.  The texture path
+//     carries half the instructions, the LDS (4x its rate) the other half, and the vector ALU -- unchanged: set-up, v_perm
+//     re-pairing, MFMA issue -- becomes the limiter;
+//   * workgroups with the same blockIdx % 8 share an XCD (private L2): plane p lives on XCD p % 8, its G workgroups sweep the
+//     queries together (run r of workgroup g, wave w: r = k * 16 G + 16 g + w);
+//   * staging (corner offsets + split weights per (point, query), private to a wave) is done in two halves -- points 0..7, then
+//     8..L*P-1, every lane preparing two (three) consecutive points of each -- so that 16 waves' staging (64-96 KiB) and the
+//     resident levels fit the CU's 160 KB.
+// The level table is a HOST argument here (the resident set is sized on the host); callers that only have the device tensors
+// use the query-run kernel.
+#include <cstdlib>
+
+#include "common.h"
+#include "msda_qrun.h"
+
+namespace rdetr {
+namespace {
+
+constexpr int kRQ = 16;                          // queries per wave and run (bf16: 4 lanes x 16 B per head row)
+constexpr unsigned kResBase = 128;               // LDS: [0, 64) zero row, [128, 128 + res_bytes) resident levels, then staging
+constexpr int kLdsBytes = 160 * 1024;
+
+struct ResArgs {
+    const uint16_t *value;
+    const void *src_a;
+    const void *src_b;
+    const float *ref;
+    uint16_t *out;
+    int h[5], w[5], start[5];
+    int ref_dim, S, Nq, B, ld_a, ld_b;
+    int lr;                                      // first resident level
+    int start_lr;                                // its first pixel
+    int res_bytes;                               // bytes of levels lr .. L-1 of one plane (multiple of 64)
+    int stage_base;                              // LDS offset of the staging area (multiple of 128)
+};
+
+// N consecutive query-side values at a stated alignment (the compiler picks the widest legal loads)
+template <int N, int ALIGN> __device__ __forceinline__ void load_f32(const float *p, float (&v)[N])
+{
+    __builtin_memcpy(v, __builtin_assume_aligned(p, ALIGN), N * 4);
+}
+template <int N, int ALIGN> __device__ __forceinline__ void load_bf16(const uint16_t *p, float (&v)[N])
+{
+    uint16_t r[N];
+    __builtin_memcpy(r, __builtin_assume_aligned(p, ALIGN), N * 2);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = bf16_bits_to_f32(r[i]);
+}
+
+// What a lane needs to know about one level: size, the pixel index whose byte offset (x 64) addresses the level's pixel 0 -- in
+// the plane (buffer path) or in the resident copy (LDS path) -- and the offset that stands for "outside" on that path.
+struct LaneLevel {
+    int h, w, st;
+    unsigned inv;
+};
+
+// RW = waves per workgroup, U = points (4 corner loads each) in flight per lane on the buffer path
+template <int LT, bool FUSED, int RW, int U>
+__global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a)
+{
+    constexpr int kRW = RW;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    constexpr int LP = LT * kPoints;
+    // Staging halves: A = points 0..7 (levels 0 and 1, two per lane), B = points 8..LP-1 (two or three per lane).  A lane's points
+    // of a half are consecutive: lane `sub` prepares 2 sub, 2 sub + 1 and 8 + kB sub .. -- every lane works in both halves, and
+    // nothing but the second half's INPUTS waits in registers over the first half's gathers.
+    constexpr int kFirstB = 2 * kPoints;
+    constexpr int kB = (LP - kFirstB) / 4;       // 2 (L = 4) or 3 (L = 5)
+    constexpr int kStagePts = LP - kFirstB;      // the larger half: 8 or 12 points
+    constexpr unsigned kStageBytes = kStagePts * kRQ * 32;
+    static_assert(LT == 4 || LT == 5, "4 or 5 levels");
+    using IO = ValueIO<uint16_t>;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = lane >> 2, sub = lane & 3;
+    const unsigned lane_off = (unsigned)sub * 16u;
+
+    // ---- which planes, which share of their runs
+    const int nx = (int)gridDim.x >> 3;                              // workgroups per XCD
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int planes = a.B * kHeads;
+    const int Jx = (planes - xcd + 7) >> 3;                          // planes p = xcd + 8 j of this XCD
+    if (Jx <= 0) return;
+    const int G = nx / Jx > 0 ? nx / Jx : 1;                         // workgroups per plane
+    const int teams = Jx < nx ? Jx : nx;
+    const int team = slot / G, g = slot - team * G;
+    if (team >= teams) return;                                       // nx not a multiple of Jx: the remainder idles
+
+    // ---- the lane's level constants, once per wave
+    auto level_of = [&](int lvl) {
+        LaneLevel c{1, 1, 0, kInvalidOffset};
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            const bool res = l >= a.lr;
+            const int st = res ? (int)(kResBase / 64) + a.start[l] - a.start_lr : a.start[l];
+            if (lvl == l) c = LaneLevel{a.h[l], a.w[l], st, res ? 0u : kInvalidOffset};
+        }
+        return c;
+    };
+    const int pA = 2 * sub, pB = kFirstB + kB * sub;                 // the lane's first point of each half
+    const int lvA = pA >> 2, lvB = pB >> 2;
+    const int lvB1 = lvB + 1 < LT ? lvB + 1 : LT - 1;                // L = 5: a lane's three points may span two levels
+    const LaneLevel cA = level_of(lvA), cB0 = level_of(lvB), cB1 = level_of(lvB1);
+    const int nB0 = kPoints - (pB & 3);                              // points k < nB0 of half B lie on level lvB
+    const int lr4 = a.lr * kPoints;
+    const float iwA = 1.0f / (float)cA.w, ihA = 1.0f / (float)cA.h;
+    const float iwB0 = 1.0f / (float)cB0.w, ihB0 = 1.0f / (float)cB0.h, iwB1 = 1.0f / (float)cB1.w, ihB1 = 1.0f / (float)cB1.h;
+
+    u32x4 *soff = reinterpret_cast<u32x4 *>(smem + a.stage_base + wave * kStageBytes);
+    f32x4 *swgt = reinterpret_cast<f32x4 *>(smem + a.stage_base + wave * kStageBytes + kStagePts * kRQ * 16);
+    const unsigned wsel = (unsigned)(sub & 1) * 8u;
+    const int runs = (a.Nq + kRQ - 1) / kRQ;
+
+    for (int j = team; j < Jx; j += teams) {
+        const int p = xcd + 8 * j, b = p >> 3, m = p & 7;
+        const uint16_t *plane = a.value + ((size_t)b * kHeads + m) * (size_t)a.S * kHeadDim;
+        __syncthreads();                                             // the previous plane's readers are done
+        if (tid < 4) *reinterpret_cast<u32x4 *>(smem + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+        {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(plane + (size_t)a.start_lr * kHeadDim);
+            const int n16 = a.res_bytes >> 4;
+#pragma unroll 4
+            for (int i = tid; i < n16; i += kRW * kWave) *reinterpret_cast<u32x4 *>(smem + kResBase + i * 16) = src[i];
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(plane), 0, (unsigned)a.S * IO::kHeadBytes, 0x00020000);
+
+        // the lane's share of a run's query-side inputs: locations / weights, or raw offsets / logits (as fp32) + reference points
+        struct Inputs {
+            float lA[4], lB[2 * kB], aA[2], aB[kB];
+            f32x4 rA, rB0, rB1;
+        };
+        auto load_inputs = [&](int r, Inputs &in) {
+            const int q = r * kRQ + qs;
+            const size_t row = (size_t)b * a.Nq + (q < a.Nq ? q : 0);
+            const size_t hrow = (row * kHeads + m) * (size_t)LP;
+            if constexpr (FUSED) {
+                const uint16_t *off_q = static_cast<const uint16_t *>(a.src_a) + (a.ld_a ? row * (size_t)a.ld_a + (size_t)m * LP * 2 : hrow * 2);
+                const uint16_t *lg_q = static_cast<const uint16_t *>(a.src_b) + (a.ld_b ? row * (size_t)a.ld_b + (size_t)m * LP : hrow);
+                load_bf16<4, (LT == 4 ? 8 : 4)>(off_q + 2 * pA, in.lA);
+                load_bf16<2 * kB, (LT == 4 ? 8 : 4)>(off_q + 2 * pB, in.lB);
+                load_bf16<2, (LT == 4 ? 4 : 2)>(lg_q + pA, in.aA);
+                load_bf16<kB, (LT == 4 ? 4 : 2)>(lg_q + pB, in.aB);
+                const float *rpA = a.ref + (row * LT + lvA) * (size_t)a.ref_dim;
+                const float *rpB0 = a.ref + (row * LT + lvB) * (size_t)a.ref_dim;
+                const float *rpB1 = a.ref + (row * LT + lvB1) * (size_t)a.ref_dim;
+                in.rA = in.rB0 = in.rB1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.ref_dim == 2) {
+                    const f32x2 t0 = *reinterpret_cast<const f32x2 *>(rpA), t1 = *reinterpret_cast<const f32x2 *>(rpB0);
+                    in.rA = f32x4{t0.x, t0.y, 0.f, 0.f};
+                    in.rB0 = f32x4{t1.x, t1.y, 0.f, 0.f};
+                    if constexpr (LT == 5) {
+                        const f32x2 t2 = *reinterpret_cast<const f32x2 *>(rpB1);
+                        in.rB1 = f32x4{t2.x, t2.y, 0.f, 0.f};
+                    }
+                } else {
+                    in.rA = *reinterpret_cast<const f32x4 *>(rpA);
+                    in.rB0 = *reinterpret_cast<const f32x4 *>(rpB0);
+                    if constexpr (LT == 5) in.rB1 = *reinterpret_cast<const f32x4 *>(rpB1);
+                }
+            } else {
+                const float *loc_q = static_cast<const float *>(a.src_a) + hrow * 2;
+                const float *att_q = static_cast<const float *>(a.src_b) + hrow;
+                load_f32<4, (LT == 4 ? 16 : 8)>(loc_q + 2 * pA, in.lA);
+                load_f32<2 * kB, (LT == 4 ? 16 : 8)>(loc_q + 2 * pB, in.lB);
+                load_f32<2, (LT == 4 ? 8 : 4)>(att_q + pA, in.aA);
+                load_f32<kB, (LT == 4 ? 8 : 4)>(att_q + pB, in.aB);
+            }
+        };
+        const int step = G * kRW;
+        int r = g * kRW + wave;
+        Inputs cur;
+        if (r < runs) load_inputs(r, cur);
+        for (; r < runs; r += step) {
+            const int q = r * kRQ + qs;
+            const bool qok = q < a.Nq;
+            const size_t row = (size_t)b * a.Nq + (qok ? q : 0);
+
+            // ---- inputs of the lane's 2 + kB points (loaded by the previous run, after its buffer-path gathers were consumed)
+            float atA[2], atB[kB];
+            f32x2 xyA[2], xyB[kB];
+            if constexpr (FUSED) {
+                // raw offsets / logits (bf16) and reference points: softmax over all L*P logits of the (query, head), then
+                // loc = ref + off / (W_l, H_l)  |  ref_xy + off / P * ref_wh * 0.5   (ms_deform_attn.py:326-349)
+                float mx = fmaxf(cur.aA[0], cur.aA[1]);
+#pragma unroll
+                for (int k = 0; k < kB; ++k) mx = fmaxf(mx, cur.aB[k]);
+                mx = group_max<4>(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    atA[k] = __builtin_amdgcn_exp2f((cur.aA[k] - mx) * 1.44269504088896341f);
+                    sum += atA[k];
+                }
+#pragma unroll
+                for (int k = 0; k < kB; ++k) {
+                    atB[k] = __builtin_amdgcn_exp2f((cur.aB[k] - mx) * 1.44269504088896341f);
+                    sum += atB[k];
+                }
+                sum = group_sum<4>(sum);
+                const float inv_sum = 1.0f / sum;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    atA[k] *= inv_sum;
+                    if (a.ref_dim == 2) {
+                        xyA[k] = f32x2{cur.rA.x + cur.lA[2 * k] * iwA, cur.rA.y + cur.lA[2 * k + 1] * ihA};
+                    } else {
+                        xyA[k] = f32x2{cur.rA.x + cur.lA[2 * k] * (1.0f / kPoints) * cur.rA.z * 0.5f,
+                                       cur.rA.y + cur.lA[2 * k + 1] * (1.0f / kPoints) * cur.rA.w * 0.5f};
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kB; ++k) {
+                    const bool second = LT == 5 && k >= nB0;
+                    const f32x4 rc = second ? cur.rB1 : cur.rB0;
+                    atB[k] *= inv_sum;
+                    if (a.ref_dim == 2) {
+                        xyB[k] = f32x2{rc.x + cur.lB[2 * k] * (second ? iwB1 : iwB0), rc.y + cur.lB[2 * k + 1] * (second ? ihB1 : ihB0)};
+                    } else {
+                        xyB[k] = f32x2{rc.x + cur.lB[2 * k] * (1.0f / kPoints) * rc.z * 0.5f, rc.y + cur.lB[2 * k + 1] * (1.0f / kPoints) * rc.w * 0.5f};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    xyA[k] = f32x2{cur.lA[2 * k], cur.lA[2 * k + 1]};
+                    atA[k] = cur.aA[k];
+                }
+#pragma unroll
+                for (int k = 0; k < kB; ++k) {
+                    xyB[k] = f32x2{cur.lB[2 * k], cur.lB[2 * k + 1]};
+                    atB[k] = cur.aB[k];
+                }
+            }
+
+            // corner offsets (bytes in the plane, or LDS addresses in the resident copy) and split weights of one point -> staging slot
+            auto stage_point = [&](const f32x2 xy, const float at, const LaneLevel &c, int slot_pt) {
+                const int h = c.h, w = c.w;
+                const float x = xy.x * (float)w - 0.5f;
+                const float y = xy.y * (float)h - 0.5f;
+                const bool inside = qok && (y > -1.f) && (x > -1.f) && (y < (float)h) && (x < (float)w);   // false for NaN
+                const float xf = floorf(x), yf = floorf(y);
+                const int x0 = inside ? (int)xf : 0, y0 = inside ? (int)yf : 0;
+                const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+                const bool okx0 = inside && x0 >= 0, okx1 = inside && x0 + 1 <= w - 1;
+                const bool oky0 = y0 >= 0, oky1 = y0 + 1 <= h - 1;
+                const unsigned base = (unsigned)(c.st + y0 * w + x0) * IO::kHeadBytes;
+                const unsigned rowb = (unsigned)w * IO::kHeadBytes;
+                u32x4 o;
+                o.x = (okx0 && oky0) ? base : c.inv;
+                o.y = (okx1 && oky0) ? base + IO::kHeadBytes : c.inv;
+                o.z = (okx0 && oky1) ? base + rowb : c.inv;
+                o.w = (okx1 && oky1) ? base + rowb + IO::kHeadBytes : c.inv;
+                const float w00 = inside ? hy * hx * at : 0.f, w01 = inside ? hy * lx * at : 0.f;
+                const float w10 = inside ? ly * hx * at : 0.f, w11 = inside ? ly * lx * at : 0.f;
+                unsigned h01, l01, h23, l23;                 // {hi(00,01), hi(10,11), lo(00,01), lo(10,11)}: A rows 0 and 1 of mfma_point
+                split2_bf16(w00, w01, h01, l01);
+                split2_bf16(w10, w11, h23, l23);
+                soff[slot_pt * kRQ + qs] = o;
+                swgt[slot_pt * kRQ + qs] = __builtin_bit_cast(f32x4, u32x4{h01, h23, l01, l23});
+            };
+
+            f32x4 accm[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) accm[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            // points [first, end) from the staged records (slot = pt - first): through the buffer descriptor below level lr, from LDS from it on
+            auto gather = [&](int first, int end) {
+                const int mid = lr4 < first ? first : (lr4 > end ? end : lr4);
+#pragma unroll U
+                for (int pt = first; pt < mid; ++pt) {       // 4 U loads of 16 B in flight per lane
+                    const int s = (pt - first) * kRQ + qs;
+                    const u32x4 o = soff[s];
+                    const u32x2 wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + s) + wsel);
+                    const u32x4 r00 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + lane_off, 0, 0);
+                    const u32x4 r01 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + lane_off, 0, 0);
+                    const u32x4 r10 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + lane_off, 0, 0);
+                    const u32x4 r11 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + lane_off, 0, 0);
+                    mfma_point(r00, r01, r10, r11, wq, accm);
+                }
+#pragma unroll 2
+                for (int pt = mid; pt < end; ++pt) {
+                    const int s = (pt - first) * kRQ + qs;
+                    const u32x4 o = soff[s];
+                    const u32x2 wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + s) + wsel);
+                    const u32x4 r00 = *reinterpret_cast<const u32x4 *>(smem + o.x + lane_off);
+                    const u32x4 r01 = *reinterpret_cast<const u32x4 *>(smem + o.y + lane_off);
+                    const u32x4 r10 = *reinterpret_cast<const u32x4 *>(smem + o.z + lane_off);
+                    const u32x4 r11 = *reinterpret_cast<const u32x4 *>(smem + o.w + lane_off);
+                    mfma_point(r00, r01, r10, r11, wq, accm);
+                }
+            };
+            auto wave_sync = [&]() {       // staging is private to the wave and LDS operations of one wave complete in order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
+
+#pragma unroll
+            for (int k = 0; k < 2; ++k) stage_point(xyA[k], atA[k], cA, pA + k);
+            wave_sync();
+            gather(0, kFirstB);
+            // the next run's inputs: asked for once this run's buffer-path data has landed (loads return in order: asked for earlier,
+            // they would hold up the first gathered row), in flight over the second half and the store
+            Inputs nxt;
+            if (r + step < runs) load_inputs(r + step, nxt);
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < kB; ++k) stage_point(xyB[k], atB[k], (LT == 5 && k >= nB0) ? cB1 : cB0, pB - kFirstB + k);
+            wave_sync();
+            gather(kFirstB, LP);
+            wave_sync();
+
+            float res[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) res[c] = accm[c].x + accm[c].y;
+            if (qok) IO::store_run(a.out + row * (kHeads * kHeadDim) + m * kHeadDim + sub * 8, res);
+            cur = nxt;
+        }
+    }
+}
+
+}  // namespace
+
+// development A/B: waves per workgroup (make dev: rdetr_dev_set_res_waves)
+struct ResVariant {
+#ifdef RDETR_DEV
+    static inline int waves = 16;
+#else
+    static constexpr int waves = 16;
+#endif
+};
+
+// Host side.  Returns RDETR_ERR_UNSUPPORTED for everything the kernel does not cover (the caller then runs the query-run kernel).
+template <bool FUSED>
+static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const int64_t *level_start, const void *src_a,
+                            const void *src_b, const float *ref, int ref_dim, int B, int S, int L, int Nq, int ld_a, int ld_b,
+                            uint16_t *out, hipStream_t stream)
+{
+    if (L != 4 && L != 5) return RDETR_ERR_UNSUPPORTED;
+    if ((long long)S * 64 >= (1ll << 31)) return RDETR_ERR_UNSUPPORTED;
+    if ((long long)B * Nq < 16384) return RDETR_ERR_UNSUPPORTED;        // too few runs to feed 256 persistent workgroups
+    ResArgs a{};
+    long long at = 0;
+    for (int l = 0; l < L; ++l) {                                        // the levels must tile [0, S): the resident copy is plane[start_lr .. S)
+        const long long h = shapes[2 * l], w = shapes[2 * l + 1];
+        if (h <= 0 || w <= 0 || h > 32768 || w > 32768 || level_start[l] != at) return RDETR_ERR_UNSUPPORTED;
+        a.h[l] = (int)h; a.w[l] = (int)w; a.start[l] = (int)at;
+        at += h * w;
+    }
+    if (at != S) return RDETR_ERR_UNSUPPORTED;
+    // alignment of the vector loads (msda_fwd.hip: vec_ok / vec5_ok)
+    const auto al = [](const void *p, uintptr_t n) { return reinterpret_cast<uintptr_t>(p) % n == 0; };
+    if (!al(value, 16) || !al(out, 16)) return RDETR_ERR_UNSUPPORTED;
+    if (L == 4) {
+        if (!al(src_a, 16) || !al(src_b, 16)) return RDETR_ERR_UNSUPPORTED;
+        if (FUSED && (!al(ref, 16) || (ld_a * 2) % 16 != 0 || (ld_b * 2) % 16 != 0)) return RDETR_ERR_UNSUPPORTED;
+    } else {
+        if (!al(src_a, 8) || !al(src_b, 4)) return RDETR_ERR_UNSUPPORTED;
+        if (FUSED && (!al(ref, 16) || (ld_a * 2) % 4 != 0)) return RDETR_ERR_UNSUPPORTED;
+    }
+    const int RW = ResVariant::waves;
+    const int stage = (L * kPoints - 2 * kPoints) * kRQ * 32 * RW;               // the larger staging half: points 8 .. L*P-1
+    const int budget = kLdsBytes - (int)kResBase - stage - 128;
+    int lr = L;
+    while (lr > 1 && ((long long)S - a.start[lr - 1]) * 64 <= budget) --lr;
+    if (lr == L) return RDETR_ERR_UNSUPPORTED;                           // not even the coarsest level fits
+    a.value = value; a.src_a = src_a; a.src_b = src_b; a.ref = ref; a.out = out;
+    a.ref_dim = ref_dim; a.S = S; a.Nq = Nq; a.B = B; a.ld_a = ld_a; a.ld_b = ld_b;
+    a.lr = lr; a.start_lr = a.start[lr]; a.res_bytes = (S - a.start[lr]) * 64;
+    a.stage_base = (int)((kResBase + a.res_bytes + 127) / 128 * 128);
+    const int lds = a.stage_base + stage;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RDETR_ERR_LAUNCH;
+        cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
+    }
+    const dim3 grid((unsigned)cus);
+    auto launch = [&](auto kern, int waves) -> int {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (attr != hipSuccess) return RDETR_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(waves * kWave), (size_t)lds, stream, a);
+        return launch_status();
+    };
+#ifdef RDETR_DEV
+    if (RW == 12) return L == 4 ? launch(msda_fwd_res_kernel<4, FUSED, 12, 4>, 12) : launch(msda_fwd_res_kernel<5, FUSED, 12, 4>, 12);
+    if (RW == 8) return L == 4 ? launch(msda_fwd_res_kernel<4, FUSED, 8, 8>, 8) : launch(msda_fwd_res_kernel<5, FUSED, 8, 8>, 8);
+#endif
+    return L == 4 ? launch(msda_fwd_res_kernel<4, FUSED, 16, 2>, 16) : launch(msda_fwd_res_kernel<5, FUSED, 16, 2>, 16);
+}
+
+}  // namespace rdetr
+
+static int res_common_checks(const void *value, const int64_t *hs, const int64_t *hl, const void *a, const void *b, const void *out, int B,
+                             int S, int H, int D, int L, int Nq, int P)
+{
+    if (B < 0 || S < 0 || Nq < 0 || H <= 0 || D <= 0 || L <= 0 || P <= 0) return RDETR_ERR_INVALID_ARG;
+    if (B == 0 || Nq == 0) return RDETR_OK;
+    if (!value || !hs || !hl || !a || !b || !out || S == 0) return RDETR_ERR_INVALID_ARG;
+    if (H != rdetr::kHeads || D != rdetr::kHeadDim || P != rdetr::kPoints) return RDETR_ERR_UNSUPPORTED;
+    return -1;                                                           // go on
+}
+
+extern "C" int rdetr_msda_forward_resident_bf16(const uint16_t *value, const int64_t *host_spatial_shapes,
+                                                const int64_t *host_level_start_index, const float *sampling_loc,
+                                                const float *attn_weight, int B, int S, int H, int D, int L, int Nq, int P,
+                                                uint16_t *out, void *stream)
+{
+    const int st = res_common_checks(value, host_spatial_shapes, host_level_start_index, sampling_loc, attn_weight, out, B, S, H, D, L, Nq, P);
+    if (st != -1) return st;
+    return rdetr::msda_res_forward<false>(value, host_spatial_shapes, host_level_start_index, sampling_loc, attn_weight, nullptr, 0, B, S,
+                                          L, Nq, 0, 0, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rdetr_msda_forward_fused_resident_bf16(const uint16_t *value, const int64_t *host_spatial_shapes,
+                                                      const int64_t *host_level_start_index, const uint16_t *sampling_offsets,
+                                                      int ld_offsets, const uint16_t *attn_logits, int ld_logits,
+                                                      const float *reference_points, int ref_dim, int B, int S, int H, int D, int L,
+                                                      int Nq, int P, uint16_t *out, void *stream)
+{
+    const int st = res_common_checks(value, host_spatial_shapes, host_level_start_index, sampling_offsets, attn_logits, out, B, S, H, D, L, Nq, P);
+    if (st != -1) return st;
+    if (!reference_points || (ref_dim != 2 && ref_dim != 4)) return RDETR_ERR_INVALID_ARG;
+    if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
+        ld_offsets % 2 != 0)
+        return RDETR_ERR_INVALID_ARG;
+    return rdetr::msda_res_forward<true>(value, host_spatial_shapes, host_level_start_index, sampling_offsets, attn_logits,
+                                         reference_points, ref_dim, B, S, L, Nq, ld_offsets, ld_logits, out,
+                                         static_cast<hipStream_t>(stream));
+}
+
+#ifdef RDETR_DEV
+extern "C" void rdetr_dev_set_res_waves(int v) { rdetr::ResVariant::waves = (v == 8 || v == 12) ? v : 16; }
+#endif

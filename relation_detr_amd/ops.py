@@ -161,8 +161,9 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
     """value [B,S,H,D] (fp32 or bf16), sampling_loc [B,Nq,H,L,P,2] fp32, attn_weight [B,Nq,H,L,P] fp32
     -> [B,Nq,H*D] in value's dtype.  ``im2col_step`` is accepted and ignored (no batch restriction).
     Not in the reference's signature (optional, bf16 only): ``value_layout="bhsd"`` for a head-major value [B,H,S,D]
-    (`value_to_head_major`), ``algo`` "auto" | "direct" | "window" | "sweep" to name the kernel (tests, A/B timing; "sweep" =
-    csrc/msda_sweep.hip, opt-in, takes the cached HOST copy of the level table)."""
+    (`value_to_head_major`), ``algo`` "auto" | "direct" | "window" | "sweep" | "resident" to name the kernel (tests, A/B timing;
+    "sweep" = csrc/msda_sweep.hip, opt-in; "resident" = csrc/msda_res.hip, what "auto" takes for a head-major value and a large
+    query count; both take the cached HOST copy of the level table)."""
     _require_device(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     _require_contiguous(value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                         sampling_loc=sampling_loc, attn_weight=attn_weight)
@@ -176,8 +177,8 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_loc")
     if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
         raise _lib.RdetrError("sampling_loc and attn_weight must be float32")
-    if algo not in ("auto", "direct", "window", "sweep"):
-        raise ValueError("algo must be 'auto', 'direct', 'window' or 'sweep'")
+    if algo not in ("auto", "direct", "window", "sweep", "resident"):
+        raise ValueError("algo must be 'auto', 'direct', 'window', 'sweep' or 'resident'")
     check_levels(spatial_shapes, level_start_index, S)
     lib = _lib.load()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
@@ -188,6 +189,17 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
                                                out.data_ptr(), _stream_ptr(value))
         _lib.check(st, "rdetr_msda_forward_sweep_bf16")
         return out
+    if value.dtype == torch.bfloat16 and value_layout == "bhsd" and algo in ("auto", "resident"):
+        # persistent workgroups with the coarse levels resident in LDS (csrc/msda_res.hip): large query counts on the head-major
+        # layout; anything it does not cover comes back as RDETR_ERR_UNSUPPORTED and runs on the query-run kernel below
+        hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
+        st = lib.rdetr_msda_forward_resident_bf16(value.data_ptr(), hs, st_h, sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                                                  B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
+        if st != _lib.ERR_UNSUPPORTED or algo == "resident":
+            _lib.check(st, "rdetr_msda_forward_resident_bf16")
+            return out
+    if algo == "resident":
+        raise _lib.RdetrError("algo='resident' needs a bfloat16 head-major value (value_layout='bhsd')")
     if value.dtype == torch.bfloat16:
         st = lib.rdetr_msda_forward_opt_bf16(value.data_ptr(), VALUE_BHSD if value_layout == "bhsd" else VALUE_BSHD,
                                              spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
@@ -288,8 +300,8 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         raise _lib.RdetrError("sampling_offsets / attn_logits must have value's dtype, reference_points float32")
     if spatial_shapes.shape[0] != L:
         raise _lib.RdetrError("spatial_shapes has a different number of levels than sampling_offsets")
-    if algo not in ("auto", "direct", "window"):
-        raise ValueError("algo must be 'auto', 'direct' or 'window'")
+    if algo not in ("auto", "direct", "window", "resident"):
+        raise ValueError("algo must be 'auto', 'direct', 'window' or 'resident'")
     if value.dtype not in (torch.float32, torch.bfloat16):
         raise _lib.RdetrError(f"value dtype {value.dtype} not supported (float32 or bfloat16)")
     if value.dtype == torch.float32 and (value_layout != "bshd" or algo != "auto"):
@@ -304,6 +316,17 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
             else key_padding_mask.to(torch.uint8).contiguous()
         mask_ptr = mask_u8.data_ptr()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
+    if (value.dtype == torch.bfloat16 and value_layout == "bhsd" and mask_ptr is None and not value_ld
+            and algo in ("auto", "resident")):
+        hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
+        st = lib.rdetr_msda_forward_fused_resident_bf16(
+            value.data_ptr(), hs, st_h, sampling_offsets.data_ptr(), ld_off, attn_logits.data_ptr(), ld_lg,
+            reference_points.data_ptr(), ref_dim, B, S, H, D, L, Nq, P, out.data_ptr(), _stream_ptr(value))
+        if st != _lib.ERR_UNSUPPORTED or algo == "resident":
+            _lib.check(st, "rdetr_msda_forward_fused_resident_bf16")
+            return out
+    if algo == "resident":
+        raise _lib.RdetrError("algo='resident' needs a bfloat16 head-major value (value_layout='bhsd') and no key_padding_mask")
     if value_ld:
         st = lib.rdetr_msda_forward_fused_strided_bf16(
             value.data_ptr(), value_ld, spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(), ld_off,

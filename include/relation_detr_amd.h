@@ -154,16 +154,16 @@ int rdetr_msda_forward_sweep_bf16(const uint16_t *value, int value_layout, const
                                   int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
 /* The bf16 operator on the RESIDENT-LEVELS kernel (csrc/msda_res.hip, round 4), head-major value [B,H,S,D] only.  Same operator
  * (ms_deform_attn_cuda_forward, ms_deform_attn_cuda.cu:12-72; kernel ms_deform_im2col_cuda.cuh:226-288), same per-query
- * arithmetic in the same order as the query-run kernel: the operator form's results are BIT-IDENTICAL to
- * rdetr_msda_forward_opt_bf16(..., RDETR_MSDA_DIRECT); the fused form differs by the summation order of the softmax
- * normaliser (an ulp of fp32).  One persistent 1024-thread workgroup per CU serves one (image, head) plane and keeps the
+ * arithmetic as the query-run kernel; the points of a query are accumulated in another order (coarse and fine levels
+ * alternate), so results agree with rdetr_msda_forward_opt_bf16(..., RDETR_MSDA_DIRECT) to fp32 re-association: the last bit
+ * of a bf16 output differs now and then (4e-5 of the outputs at the R50 shape).  One persistent 1024-thread workgroup per CU serves one (image, head) plane and keeps the
  * plane's COARSE levels -- as many trailing levels as fit beside the staging area in the CU's 160 KB of LDS (levels 2 and 3
  * at the R50 800 x 1333 shape: half of all samples) -- resident in LDS: samples on those levels read their corner rows with
  * ds_read_b128 instead of through the texture path, whose instruction rate bounds the query-run kernel.
  * The LEVEL TABLE is passed as HOST pointers (the resident set is sized on the host; the reference reads spatial_shapes on
  * the host too, ms_deform_attn.py:313); the levels must tile [0, S).  RDETR_ERR_UNSUPPORTED -- callers then use the
- * query-run kernel -- for: L other than 4 or 5, B * Nq < 16384, a level table that does not tile [0, S), not even the coarsest
- * level fitting, inputs that miss the vector-load alignment (sampling_loc / attn_weight 16 bytes at L = 4). */
+ * query-run kernel -- for: L other than 4 or 5, a level table that does not tile [0, S), not even the coarsest level fitting,
+ * inputs that miss the vector-load alignment (sampling_loc / attn_weight 16 bytes at L = 4). */
 int rdetr_msda_forward_resident_bf16(const uint16_t *value_bhsd, const int64_t *host_spatial_shapes,
                                      const int64_t *host_level_start_index, const float *sampling_loc, const float *attn_weight,
                                      int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);

@@ -23,6 +23,7 @@
 // The level table is a HOST argument here (the resident set is sized on the host); callers that only have the device tensors
 // use the query-run kernel.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "msda_qrun.h"
@@ -68,20 +69,22 @@ struct LaneLevel {
     unsigned inv;
 };
 
-// RW = waves per workgroup, U = points (4 corner loads each) in flight per lane on the buffer path
-template <int LT, bool FUSED, int RW, int U>
+// RW = waves per workgroup, LR = first resident level (LT - 2 or LT - 1): which path a point takes is known at compile time, so
+// the rounds are straight-line code (with a run-time branch per point hipcc kept two sets of accumulators: 32 registers)
+// DBG (development builds: component timing, wrong results): 1 = the fine points read the LDS zero row instead of the plane (no
+// gathers on the texture path), 2 = the coarse points read the zero row (no bank conflicts), 4 = no set-up arithmetic (constant
+// offsets and weights), 8 = no matrix-core steps
+template <int LT, bool FUSED, int RW, int LR, int DBG = 0>
 __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a)
 {
     constexpr int kRW = RW;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     constexpr int LP = LT * kPoints;
-    // Staging halves: A = points 0..7 (levels 0 and 1, two per lane), B = points 8..LP-1 (two or three per lane).  A lane's points
-    // of a half are consecutive: lane `sub` prepares 2 sub, 2 sub + 1 and 8 + kB sub .. -- every lane works in both halves, and
-    // nothing but the second half's INPUTS waits in registers over the first half's gathers.
+    // A lane prepares two consecutive points of levels 0 / 1 (points 0..7: 2 sub, 2 sub + 1) and two (three) consecutive points of
+    // the coarse levels (points 8..L*P-1: 8 + kB sub ..): every lane has work in both groups, and its loads stay vectors.
     constexpr int kFirstB = 2 * kPoints;
     constexpr int kB = (LP - kFirstB) / 4;       // 2 (L = 4) or 3 (L = 5)
-    constexpr int kStagePts = LP - kFirstB;      // the larger half: 8 or 12 points
-    constexpr unsigned kStageBytes = kStagePts * kRQ * 32;
+    constexpr unsigned kStageBytes = LP * kRQ * 16;          // per wave: the split corner weights of all L*P points of 16 queries
     static_assert(LT == 4 || LT == 5, "4 or 5 levels");
     using IO = ValueIO<uint16_t>;
 
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
         LaneLevel c{1, 1, 0, kInvalidOffset};
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
-            const bool res = l >= a.lr;
+            const bool res = l >= LR;
             const int st = res ? (int)(kResBase / 64) + a.start[l] - a.start_lr : a.start[l];
             if (lvl == l) c = LaneLevel{a.h[l], a.w[l], st, res ? 0u : kInvalidOffset};
         }
@@ -117,12 +120,12 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
     const int lvB1 = lvB + 1 < LT ? lvB + 1 : LT - 1;                // L = 5: a lane's three points may span two levels
     const LaneLevel cA = level_of(lvA), cB0 = level_of(lvB), cB1 = level_of(lvB1);
     const int nB0 = kPoints - (pB & 3);                              // points k < nB0 of half B lie on level lvB
-    const int lr4 = a.lr * kPoints;
+    constexpr int lr4 = LR * kPoints;
+    static_assert(LR >= 2 && LR < LT, "levels 0 and 1 always come through the buffer path");
     const float iwA = 1.0f / (float)cA.w, ihA = 1.0f / (float)cA.h;
     const float iwB0 = 1.0f / (float)cB0.w, ihB0 = 1.0f / (float)cB0.h, iwB1 = 1.0f / (float)cB1.w, ihB1 = 1.0f / (float)cB1.h;
 
-    u32x4 *soff = reinterpret_cast<u32x4 *>(smem + a.stage_base + wave * kStageBytes);
-    f32x4 *swgt = reinterpret_cast<f32x4 *>(smem + a.stage_base + wave * kStageBytes + kStagePts * kRQ * 16);
+    f32x4 *swgt = reinterpret_cast<f32x4 *>(smem + a.stage_base + wave * kStageBytes);
     const unsigned wsel = (unsigned)(sub & 1) * 8u;
     const int runs = (a.Nq + kRQ - 1) / kRQ;
 
@@ -249,8 +252,13 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
                 }
             }
 
-            // corner offsets (bytes in the plane, or LDS addresses in the resident copy) and split weights of one point -> staging slot
-            auto stage_point = [&](const f32x2 xy, const float at, const LaneLevel &c, int slot_pt) {
+            // corner offsets (bytes in the plane, or LDS addresses in the resident copy) of one point -> returned (they stay in the
+            // lane's registers); its split weights -> the wave's staging slot of that point
+            auto setup_point = [&](const f32x2 xy, const float at, const LaneLevel &c, int pt) -> u32x4 {
+                if constexpr ((DBG & 4) != 0) {
+                    swgt[pt * kRQ + qs] = f32x4{xy.x, xy.y, at, at};
+                    return u32x4{c.inv, c.inv, c.inv, c.inv};
+                }
                 const int h = c.h, w = c.w;
                 const float x = xy.x * (float)w - 0.5f;
                 const float y = xy.y * (float)h - 0.5f;
@@ -272,60 +280,112 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
                 unsigned h01, l01, h23, l23;                 // {hi(00,01), hi(10,11), lo(00,01), lo(10,11)}: A rows 0 and 1 of mfma_point
                 split2_bf16(w00, w01, h01, l01);
                 split2_bf16(w10, w11, h23, l23);
-                soff[slot_pt * kRQ + qs] = o;
-                swgt[slot_pt * kRQ + qs] = __builtin_bit_cast(f32x4, u32x4{h01, h23, l01, l23});
+                swgt[pt * kRQ + qs] = __builtin_bit_cast(f32x4, u32x4{h01, h23, l01, l23});
+                return o;
             };
+            u32x4 oA[2], oB[kB];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) oA[k] = setup_point(xyA[k], atA[k], cA, pA + k);
+#pragma unroll
+            for (int k = 0; k < kB; ++k) oB[k] = setup_point(xyB[k], atB[k], (LT == 5 && k >= nB0) ? cB1 : cB0, pB + k);
+            // the weights are private to the wave and LDS operations of one wave complete in order: a wave-level fence, no s_barrier
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             f32x4 accm[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) accm[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-            // points [first, end) from the staged records (slot = pt - first): through the buffer descriptor below level lr, from LDS from it on
-            auto gather = [&](int first, int end) {
-                const int mid = lr4 < first ? first : (lr4 > end ? end : lr4);
-#pragma unroll U
-                for (int pt = first; pt < mid; ++pt) {       // 4 U loads of 16 B in flight per lane
-                    const int s = (pt - first) * kRQ + qs;
-                    const u32x4 o = soff[s];
-                    const u32x2 wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + s) + wsel);
-                    const u32x4 r00 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + lane_off, 0, 0);
-                    const u32x4 r01 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + lane_off, 0, 0);
-                    const u32x4 r10 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + lane_off, 0, 0);
-                    const u32x4 r11 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + lane_off, 0, 0);
-                    mfma_point(r00, r01, r10, r11, wq, accm);
-                }
-#pragma unroll 2
-                for (int pt = mid; pt < end; ++pt) {
-                    const int s = (pt - first) * kRQ + qs;
-                    const u32x4 o = soff[s];
-                    const u32x2 wq = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + s) + wsel);
-                    const u32x4 r00 = *reinterpret_cast<const u32x4 *>(smem + o.x + lane_off);
-                    const u32x4 r01 = *reinterpret_cast<const u32x4 *>(smem + o.y + lane_off);
-                    const u32x4 r10 = *reinterpret_cast<const u32x4 *>(smem + o.z + lane_off);
-                    const u32x4 r11 = *reinterpret_cast<const u32x4 *>(smem + o.w + lane_off);
-                    mfma_point(r00, r01, r10, r11, wq, accm);
-                }
+            // Point PT (compile time) of the 16 queries: its four corner addresses = the owner lane's offsets broadcast over the
+            // query's 4 lanes inside the address add (DPP quad_perm: no LDS round trip, no extra instruction) + the lane's 16 bytes
+            auto corner_addr = [&](auto PT) -> u32x4 {
+                constexpr int pt = decltype(PT)::value;
+                constexpr bool in_a = pt < kFirstB;
+                constexpr int own = in_a ? pt / 2 : (pt - kFirstB) / kB, k = in_a ? pt % 2 : (pt - kFirstB) % kB;
+                constexpr int ctrl = own * 0x55;             // quad_perm:[own, own, own, own]
+                const u32x4 o = in_a ? oA[k] : oB[k];
+                return u32x4{(unsigned)__builtin_amdgcn_update_dpp(0, (int)o.x, ctrl, 0xf, 0xf, true) + lane_off,
+                             (unsigned)__builtin_amdgcn_update_dpp(0, (int)o.y, ctrl, 0xf, 0xf, true) + lane_off,
+                             (unsigned)__builtin_amdgcn_update_dpp(0, (int)o.z, ctrl, 0xf, 0xf, true) + lane_off,
+                             (unsigned)__builtin_amdgcn_update_dpp(0, (int)o.w, ctrl, 0xf, 0xf, true) + lane_off};
             };
-            auto wave_sync = [&]() {       // staging is private to the wave and LDS operations of one wave complete in order
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            auto weights_of = [&](int pt) {
+                return *reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned char *>(swgt + pt * kRQ + qs) + wsel);
             };
-
-#pragma unroll
-            for (int k = 0; k < 2; ++k) stage_point(xyA[k], atA[k], cA, pA + k);
-            wave_sync();
-            gather(0, kFirstB);
-            // the next run's inputs: asked for once this run's buffer-path data has landed (loads return in order: asked for earlier,
-            // they would hold up the first gathered row), in flight over the second half and the store
+            struct Rows { u32x4 r00, r01, r10, r11; };
+            auto from_plane = [&](const u32x4 ad) {
+                if constexpr ((DBG & 1) != 0) return Rows{*reinterpret_cast<const u32x4 *>(smem + lane_off), *reinterpret_cast<const u32x4 *>(smem + lane_off + (ad.x & 0u)),
+                                                        *reinterpret_cast<const u32x4 *>(smem + lane_off + (ad.y & 0u)), *reinterpret_cast<const u32x4 *>(smem + lane_off + (ad.z & 0u))};
+                return Rows{__builtin_amdgcn_raw_buffer_load_b128(rsrc, ad.x, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsrc, ad.y, 0, 0),
+                            __builtin_amdgcn_raw_buffer_load_b128(rsrc, ad.z, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsrc, ad.w, 0, 0)};
+            };
+            auto from_lds = [&](const u32x4 ad) {
+                if constexpr ((DBG & 2) != 0) return Rows{*reinterpret_cast<const u32x4 *>(smem + lane_off), *reinterpret_cast<const u32x4 *>(smem + lane_off + (ad.x & 0u)),
+                                                        *reinterpret_cast<const u32x4 *>(smem + lane_off + (ad.y & 0u)), *reinterpret_cast<const u32x4 *>(smem + lane_off + (ad.z & 0u))};
+                return Rows{*reinterpret_cast<const u32x4 *>(smem + ad.x), *reinterpret_cast<const u32x4 *>(smem + ad.y),
+                            *reinterpret_cast<const u32x4 *>(smem + ad.z), *reinterpret_cast<const u32x4 *>(smem + ad.w)};
+            };
+            // Eight steps, one point of levels 0 / 1 (the plane, through the buffer descriptor) each.  Step i: ask for the corner rows of
+            // point i + 1, work off this step's share of the coarse points (resident: LDS reads; else the plane), then take in point
+            // i's rows, which have been travelling since the step before.  The accumulation order is therefore 8, 0, 9, 1, ... --
+            // not the query-run kernel's 0 .. 15: results agree to fp32 re-association (the last bit of a bf16 output now and then).
+            constexpr int kCoarse = LP - kFirstB;            // 8 or 12
             Inputs nxt;
-            if (r + step < runs) load_inputs(r + step, nxt);
-            wave_sync();
-#pragma unroll
-            for (int k = 0; k < kB; ++k) stage_point(xyB[k], atB[k], (LT == 5 && k >= nB0) ? cB1 : cB0, pB - kFirstB + k);
-            wave_sync();
-            gather(kFirstB, LP);
-            wave_sync();
+            auto consume = [&](const Rows &rw, const u32x2 wq) {
+                if constexpr ((DBG & 8) != 0) {
+                    accm[0].x += __builtin_bit_cast(float, rw.r00.x ^ rw.r01.y ^ rw.r10.z ^ rw.r11.w ^ wq.x);
+                } else {
+                    mfma_point(rw.r00, rw.r01, rw.r10, rw.r11, wq, accm);
+                }
+            };
+            auto coarse = [&](auto PT) {
+                constexpr int pt = decltype(PT)::value;
+                const u32x4 ad = corner_addr(PT);
+                const u32x2 wq = weights_of(pt);
+                if constexpr (pt >= lr4) {
+                    const Rows b = from_lds(ad);
+                    consume(b, wq);
+                } else {
+                    const Rows b = from_plane(ad);
+                    consume(b, wq);
+                }
+            };
+            // kAhead = how many steps ahead a fine point's rows are asked for; kLoose: no fences inside a step (two waves per SIMD have
+            // 256 registers each: let the compiler overlap the coarse points' LDS round trips)
+            constexpr int kAhead = RW == 8 ? 2 : 1;
+            constexpr bool kLoose = RW == 8;
+            Rows fine[kFirstB];
+            fine[0] = from_plane(corner_addr(std::integral_constant<int, 0>{}));
+            if constexpr (kAhead == 2) fine[1] = from_plane(corner_addr(std::integral_constant<int, 1>{}));
+            auto step_fn = [&](auto I) {
+                constexpr int i = decltype(I)::value;
+                __builtin_amdgcn_sched_barrier(0);           // a step's addresses are formed in the step (registers)
+                if constexpr (i + kAhead < kFirstB) fine[i + kAhead] = from_plane(corner_addr(std::integral_constant<int, i + kAhead>{}));
+                if constexpr (i + kAhead + 1 == kFirstB) {
+                    // the next run's inputs: behind this run's last plane rows (loads return in order: asked for earlier they would
+                    // hold up every step), in flight over the last steps, the store and the loop top
+                    if (r + step < runs) load_inputs(r + step, nxt);
+                }
+                constexpr int c0 = kFirstB + (i * kCoarse) / kFirstB, c1 = kFirstB + ((i + 1) * kCoarse) / kFirstB;
+                if constexpr (!kLoose) __builtin_amdgcn_sched_barrier(0);
+                coarse(std::integral_constant<int, c0>{});
+                if constexpr (c1 - c0 == 2) {
+                    if constexpr (!kLoose) __builtin_amdgcn_sched_barrier(0);       // one coarse point at a time: 16 registers of rows
+                    coarse(std::integral_constant<int, c0 + 1>{});
+                }
+                if constexpr (!kLoose) __builtin_amdgcn_sched_barrier(0);
+                consume(fine[i], weights_of(i));
+            };
+            step_fn(std::integral_constant<int, 0>{});
+            step_fn(std::integral_constant<int, 1>{});
+            step_fn(std::integral_constant<int, 2>{});
+            step_fn(std::integral_constant<int, 3>{});
+            step_fn(std::integral_constant<int, 4>{});
+            step_fn(std::integral_constant<int, 5>{});
+            step_fn(std::integral_constant<int, 6>{});
+            step_fn(std::integral_constant<int, 7>{});
+            static_assert(kFirstB == 8, "eight steps");
 
             float res[8];
 #pragma unroll
@@ -341,9 +401,10 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
 // development A/B: waves per workgroup (make dev: rdetr_dev_set_res_waves)
 struct ResVariant {
 #ifdef RDETR_DEV
-    static inline int waves = 16;
+    static inline int waves = 12;
+    static inline int dbg = 0;
 #else
-    static constexpr int waves = 16;
+    static constexpr int waves = 12;
 #endif
 };
 
@@ -355,7 +416,6 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
 {
     if (L != 4 && L != 5) return RDETR_ERR_UNSUPPORTED;
     if ((long long)S * 64 >= (1ll << 31)) return RDETR_ERR_UNSUPPORTED;
-    if ((long long)B * Nq < 16384) return RDETR_ERR_UNSUPPORTED;        // too few runs to feed 256 persistent workgroups
     ResArgs a{};
     long long at = 0;
     for (int l = 0; l < L; ++l) {                                        // the levels must tile [0, S): the resident copy is plane[start_lr .. S)
@@ -376,10 +436,10 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
         if (FUSED && (!al(ref, 16) || (ld_a * 2) % 4 != 0)) return RDETR_ERR_UNSUPPORTED;
     }
     const int RW = ResVariant::waves;
-    const int stage = (L * kPoints - 2 * kPoints) * kRQ * 32 * RW;               // the larger staging half: points 8 .. L*P-1
+    const int stage = L * kPoints * kRQ * 16 * RW;                               // weights of all points, per wave
     const int budget = kLdsBytes - (int)kResBase - stage - 128;
     int lr = L;
-    while (lr > 1 && ((long long)S - a.start[lr - 1]) * 64 <= budget) --lr;
+    while (lr > L - 2 && ((long long)S - a.start[lr - 1]) * 64 <= budget) --lr;  // one or two resident levels (the kernel's LR)
     if (lr == L) return RDETR_ERR_UNSUPPORTED;                           // not even the coarsest level fits
     a.value = value; a.src_a = src_a; a.src_b = src_b; a.ref = ref; a.out = out;
     a.ref_dim = ref_dim; a.S = S; a.Nq = Nq; a.B = B; a.ld_a = ld_a; a.ld_b = ld_b;
@@ -400,11 +460,37 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
         hipLaunchKernelGGL(kern, grid, dim3(waves * kWave), (size_t)lds, stream, a);
         return launch_status();
     };
+    const bool two = lr == L - 2;
 #ifdef RDETR_DEV
-    if (RW == 12) return L == 4 ? launch(msda_fwd_res_kernel<4, FUSED, 12, 4>, 12) : launch(msda_fwd_res_kernel<5, FUSED, 12, 4>, 12);
-    if (RW == 8) return L == 4 ? launch(msda_fwd_res_kernel<4, FUSED, 8, 8>, 8) : launch(msda_fwd_res_kernel<5, FUSED, 8, 8>, 8);
+    if (ResVariant::dbg && L == 4 && !FUSED && two) {
+        if constexpr (!FUSED) {
+            switch (ResVariant::dbg) {
+            case 1: return launch(msda_fwd_res_kernel<4, false, 12, 2, 1>, 12);
+            case 2: return launch(msda_fwd_res_kernel<4, false, 12, 2, 2>, 12);
+            case 3: return launch(msda_fwd_res_kernel<4, false, 12, 2, 3>, 12);
+            case 4: return launch(msda_fwd_res_kernel<4, false, 12, 2, 4>, 12);
+            case 7: return launch(msda_fwd_res_kernel<4, false, 12, 2, 7>, 12);
+            case 8: return launch(msda_fwd_res_kernel<4, false, 12, 2, 8>, 12);
+            case 9: return launch(msda_fwd_res_kernel<4, false, 12, 2, 9>, 12);
+            case 11: return launch(msda_fwd_res_kernel<4, false, 12, 2, 11>, 12);
+            case 12: return launch(msda_fwd_res_kernel<4, false, 12, 2, 12>, 12);
+            case 15: return launch(msda_fwd_res_kernel<4, false, 12, 2, 15>, 12);
+            default: break;
+            }
+        }
+    }
+    if (RW == 16) {
+        if (L == 4) return two ? launch(msda_fwd_res_kernel<4, FUSED, 16, 2>, 16) : launch(msda_fwd_res_kernel<4, FUSED, 16, 3>, 16);
+        return two ? launch(msda_fwd_res_kernel<5, FUSED, 16, 3>, 16) : launch(msda_fwd_res_kernel<5, FUSED, 16, 4>, 16);
+    }
+    if (RW == 8) {
+        if (L == 4) return two ? launch(msda_fwd_res_kernel<4, FUSED, 8, 2>, 8) : launch(msda_fwd_res_kernel<4, FUSED, 8, 3>, 8);
+        return two ? launch(msda_fwd_res_kernel<5, FUSED, 8, 3>, 8) : launch(msda_fwd_res_kernel<5, FUSED, 8, 4>, 8);
+    }
 #endif
-    return L == 4 ? launch(msda_fwd_res_kernel<4, FUSED, 16, 2>, 16) : launch(msda_fwd_res_kernel<5, FUSED, 16, 2>, 16);
+    // 12 waves = 3 per SIMD = 168 registers each: the rounds need ~160 (16 waves: spills, 170 us; 8 waves: the same time as 12)
+    if (L == 4) return two ? launch(msda_fwd_res_kernel<4, FUSED, 12, 2>, 12) : launch(msda_fwd_res_kernel<4, FUSED, 12, 3>, 12);
+    return two ? launch(msda_fwd_res_kernel<5, FUSED, 12, 3>, 12) : launch(msda_fwd_res_kernel<5, FUSED, 12, 4>, 12);
 }
 
 }  // namespace rdetr
@@ -448,5 +534,6 @@ extern "C" int rdetr_msda_forward_fused_resident_bf16(const uint16_t *value, con
 }
 
 #ifdef RDETR_DEV
-extern "C" void rdetr_dev_set_res_waves(int v) { rdetr::ResVariant::waves = (v == 8 || v == 12) ? v : 16; }
+extern "C" void rdetr_dev_set_res_dbg(int v) { rdetr::ResVariant::dbg = v; }
+extern "C" void rdetr_dev_set_res_waves(int v) { rdetr::ResVariant::waves = (v == 8 || v == 16) ? v : 12; }
 #endif

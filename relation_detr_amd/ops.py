@@ -145,6 +145,12 @@ def _msda_algo(algo: str, spatial_shapes, level_start_index, num_value: int) -> 
     return MSDA_AUTO_PACKED if ok else MSDA_DIRECT
 
 
+def _resident_pays(B: int, Nq: int, L: int) -> bool:
+    """'auto' on a head-major bf16 value: the resident-levels kernel (csrc/msda_res.hip: one persistent workgroup per CU) where it
+    was measured faster than the query-run kernel -- four levels and enough runs of 16 queries to feed 256 workgroups."""
+    return L == 4 and B * Nq >= 16384
+
+
 def _value_dims(value: torch.Tensor, layout: str):
     """(B, S, H, D) of a value tensor in layout "bshd" ([B,S,H,D], the reference operator's) or "bhsd" (head-major)."""
     if value.dim() != 4 or layout not in ("bshd", "bhsd"):
@@ -189,7 +195,7 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
                                                out.data_ptr(), _stream_ptr(value))
         _lib.check(st, "rdetr_msda_forward_sweep_bf16")
         return out
-    if value.dtype == torch.bfloat16 and value_layout == "bhsd" and algo in ("auto", "resident"):
+    if value.dtype == torch.bfloat16 and value_layout == "bhsd" and (algo == "resident" or (algo == "auto" and _resident_pays(B, Nq, L))):
         # persistent workgroups with the coarse levels resident in LDS (csrc/msda_res.hip): large query counts on the head-major
         # layout; anything it does not cover comes back as RDETR_ERR_UNSUPPORTED and runs on the query-run kernel below
         hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
@@ -317,7 +323,7 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         mask_ptr = mask_u8.data_ptr()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
     if (value.dtype == torch.bfloat16 and value_layout == "bhsd" and mask_ptr is None and not value_ld
-            and algo in ("auto", "resident")):
+            and (algo == "resident" or (algo == "auto" and _resident_pays(B, Nq, L)))):
         hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
         st = lib.rdetr_msda_forward_fused_resident_bf16(
             value.data_ptr(), hs, st_h, sampling_offsets.data_ptr(), ld_off, attn_logits.data_ptr(), ld_lg,

@@ -168,7 +168,8 @@ int rdetr_msda_forward_resident_bf16(const uint16_t *value_bhsd, const int64_t *
                                      const int64_t *host_level_start_index, const float *sampling_loc, const float *attn_weight,
                                      int B, int S, int H, int D, int L, int Nq, int P, uint16_t *out, void *stream);
 /* ... and its fused-producer form (arguments as rdetr_msda_forward_fused_opt_bf16; no key_padding_mask: the head-major
- * value's padded rows are zero already). */
+ * value's padded rows are zero already; 2-d reference points only -- ref_dim == 4 is RDETR_ERR_UNSUPPORTED here and runs on the
+ * query-run kernel). */
 int rdetr_msda_forward_fused_resident_bf16(const uint16_t *value_bhsd, const int64_t *host_spatial_shapes,
                                            const int64_t *host_level_start_index, const uint16_t *sampling_offsets,
                                            int ld_offsets, const uint16_t *attn_logits, int ld_logits,

@@ -42,11 +42,15 @@ struct ResArgs {
     const float *ref;
     uint16_t *out;
     int h[5], w[5], start[5];
-    int ref_dim, S, Nq, B, ld_a, ld_b;
+    int S, Nq, B, ld_a, ld_b;
     int lr;                                      // first resident level
     int start_lr;                                // its first pixel
     int res_bytes;                               // bytes of levels lr .. L-1 of one plane (multiple of 64)
     int stage_base;                              // LDS offset of the staging area (multiple of 128)
+    // Nq == S (the queries are the pyramid's pixels): a run is a 4 x 4 TILE of one level instead of 16 consecutive pixels
+    int tiled, runs;                             // runs = tiles of all levels | ceil(Nq / 16)
+    int tpre[5], tw[5];                          // tiles before level l, tiles per tile row
+    float inv_tw[5];
 };
 
 // N consecutive query-side values at a stated alignment (the compiler picks the widest legal loads)
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
 
     f32x4 *swgt = reinterpret_cast<f32x4 *>(smem + a.stage_base + wave * kStageBytes);
     const unsigned wsel = (unsigned)(sub & 1) * 8u;
-    const int runs = (a.Nq + kRQ - 1) / kRQ;
+    const int runs = a.runs;
 
     for (int j = team; j < Jx; j += teams) {
         const int p = xcd + 8 * j, b = p >> 3, m = p & 7;
@@ -144,39 +148,53 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(plane), 0, (unsigned)a.S * IO::kHeadBytes, 0x00020000);
 
+        // the lane's query of run r.  Tiled (encoder): 16 consecutive pixels of a row sample a strip of (16 + spread) x (1 + spread)
+        // pixels of their own level, a 4 x 4 tile (4 + spread)^2 -- a third fewer distinct rows per gather instruction, and the 8-12
+        // tiles a workgroup's waves hold at a time form one patch whose rows largely stay in the CU's L1 (the texture path's time
+        // per instruction grows with the lines it misses).  The order of the queries changes nothing in any query's result.
+        auto query_of = [&](int r, bool &ok) -> int {
+            if (!a.tiled) {
+                const int q = r * kRQ + qs;
+                ok = q < a.Nq;
+                return q;
+            }
+            int tp = 0, tw = a.tw[0], w = a.w[0], h = a.h[0], st = a.start[0];
+            float itw = a.inv_tw[0];
+#pragma unroll
+            for (int l = 1; l < LT; ++l) {
+                const bool ge = r >= a.tpre[l];
+                tp = ge ? a.tpre[l] : tp; tw = ge ? a.tw[l] : tw; w = ge ? a.w[l] : w; h = ge ? a.h[l] : h; st = ge ? a.start[l] : st;
+                itw = ge ? a.inv_tw[l] : itw;
+            }
+            const int u = r - tp;
+            const int ty = (int)(((float)u + 0.5f) * itw), tx = u - ty * tw;      // exact: u < 2^21
+            const int y = 4 * ty + (qs >> 2), x = 4 * tx + (qs & 3);
+            ok = y < h && x < w;
+            return st + y * w + x;
+        };
         // the lane's share of a run's query-side inputs: locations / weights, or raw offsets / logits (as fp32) + reference points
         struct Inputs {
-            float lA[4], lB[2 * kB], aA[2], aB[kB];
-            f32x4 rA, rB0, rB1;
+            float lA[4], lB[2 * kB], aA[2], aB[kB];         // operator form: locations (x, y) and weights
+            unsigned oA[2], oB[kB], gA, gB[(kB + 1) / 2];    // fused form: raw offsets and logits, two bf16 per register
+            f32x2 rA, rB0, rB1;                              // fused form: reference points (x, y) of the lane's levels
         };
         auto load_inputs = [&](int r, Inputs &in) {
-            const int q = r * kRQ + qs;
-            const size_t row = (size_t)b * a.Nq + (q < a.Nq ? q : 0);
+            bool q_ok;
+            const int q = query_of(r, q_ok);
+            const size_t row = (size_t)b * a.Nq + (q_ok ? q : 0);
             const size_t hrow = (row * kHeads + m) * (size_t)LP;
             if constexpr (FUSED) {
                 const uint16_t *off_q = static_cast<const uint16_t *>(a.src_a) + (a.ld_a ? row * (size_t)a.ld_a + (size_t)m * LP * 2 : hrow * 2);
                 const uint16_t *lg_q = static_cast<const uint16_t *>(a.src_b) + (a.ld_b ? row * (size_t)a.ld_b + (size_t)m * LP : hrow);
-                load_bf16<4, (LT == 4 ? 8 : 4)>(off_q + 2 * pA, in.lA);
-                load_bf16<2 * kB, (LT == 4 ? 8 : 4)>(off_q + 2 * pB, in.lB);
-                load_bf16<2, (LT == 4 ? 4 : 2)>(lg_q + pA, in.aA);
-                load_bf16<kB, (LT == 4 ? 4 : 2)>(lg_q + pB, in.aB);
-                const float *rpA = a.ref + (row * LT + lvA) * (size_t)a.ref_dim;
-                const float *rpB0 = a.ref + (row * LT + lvB) * (size_t)a.ref_dim;
-                const float *rpB1 = a.ref + (row * LT + lvB1) * (size_t)a.ref_dim;
-                in.rA = in.rB0 = in.rB1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.ref_dim == 2) {
-                    const f32x2 t0 = *reinterpret_cast<const f32x2 *>(rpA), t1 = *reinterpret_cast<const f32x2 *>(rpB0);
-                    in.rA = f32x4{t0.x, t0.y, 0.f, 0.f};
-                    in.rB0 = f32x4{t1.x, t1.y, 0.f, 0.f};
-                    if constexpr (LT == 5) {
-                        const f32x2 t2 = *reinterpret_cast<const f32x2 *>(rpB1);
-                        in.rB1 = f32x4{t2.x, t2.y, 0.f, 0.f};
-                    }
-                } else {
-                    in.rA = *reinterpret_cast<const f32x4 *>(rpA);
-                    in.rB0 = *reinterpret_cast<const f32x4 *>(rpB0);
-                    if constexpr (LT == 5) in.rB1 = *reinterpret_cast<const f32x4 *>(rpB1);
-                }
+                __builtin_memcpy(in.oA, __builtin_assume_aligned(off_q + 2 * pA, (LT == 4 ? 8 : 4)), 8);
+                __builtin_memcpy(in.oB, __builtin_assume_aligned(off_q + 2 * pB, (LT == 4 ? 8 : 4)), 4 * kB);
+                __builtin_memcpy(&in.gA, __builtin_assume_aligned(lg_q + pA, (LT == 4 ? 4 : 2)), 4);
+                in.gB[(kB + 1) / 2 - 1] = 0u;
+                __builtin_memcpy(in.gB, __builtin_assume_aligned(lg_q + pB, (LT == 4 ? 4 : 2)), 2 * kB);
+                in.rA = *reinterpret_cast<const f32x2 *>(a.ref + (row * LT + lvA) * 2);
+                in.rB0 = *reinterpret_cast<const f32x2 *>(a.ref + (row * LT + lvB) * 2);
+                in.rB1 = f32x2{0.f, 0.f};
+                if constexpr (LT == 5) in.rB1 = *reinterpret_cast<const f32x2 *>(a.ref + (row * LT + lvB1) * 2);
             } else {
                 const float *loc_q = static_cast<const float *>(a.src_a) + hrow * 2;
                 const float *att_q = static_cast<const float *>(a.src_b) + hrow;
@@ -191,8 +209,8 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
         Inputs cur;
         if (r < runs) load_inputs(r, cur);
         for (; r < runs; r += step) {
-            const int q = r * kRQ + qs;
-            const bool qok = q < a.Nq;
+            bool qok;
+            const int q = query_of(r, qok);
             const size_t row = (size_t)b * a.Nq + (qok ? q : 0);
 
             // ---- inputs of the lane's 2 + kB points (loaded by the previous run, after its buffer-path gathers were consumed)
@@ -200,7 +218,17 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
             f32x2 xyA[2], xyB[kB];
             if constexpr (FUSED) {
                 // raw offsets / logits (bf16) and reference points: softmax over all L*P logits of the (query, head), then
-                // loc = ref + off / (W_l, H_l)  |  ref_xy + off / P * ref_wh * 0.5   (ms_deform_attn.py:326-349)
+                // loc = ref + off / (W_l, H_l)   (ms_deform_attn.py:326-336: 2-d reference points, the encoder's; the 4-d form runs on
+                // the query-run kernel)
+                auto lo16 = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+                auto hi16 = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+                cur.aA[0] = lo16(cur.gA); cur.aA[1] = hi16(cur.gA);
+#pragma unroll
+                for (int k = 0; k < kB; ++k) cur.aB[k] = (k & 1) ? hi16(cur.gB[k / 2]) : lo16(cur.gB[k / 2]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { cur.lA[2 * k] = lo16(cur.oA[k]); cur.lA[2 * k + 1] = hi16(cur.oA[k]); }
+#pragma unroll
+                for (int k = 0; k < kB; ++k) { cur.lB[2 * k] = lo16(cur.oB[k]); cur.lB[2 * k + 1] = hi16(cur.oB[k]); }
                 float mx = fmaxf(cur.aA[0], cur.aA[1]);
 #pragma unroll
                 for (int k = 0; k < kB; ++k) mx = fmaxf(mx, cur.aB[k]);
@@ -221,23 +249,14 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     atA[k] *= inv_sum;
-                    if (a.ref_dim == 2) {
-                        xyA[k] = f32x2{cur.rA.x + cur.lA[2 * k] * iwA, cur.rA.y + cur.lA[2 * k + 1] * ihA};
-                    } else {
-                        xyA[k] = f32x2{cur.rA.x + cur.lA[2 * k] * (1.0f / kPoints) * cur.rA.z * 0.5f,
-                                       cur.rA.y + cur.lA[2 * k + 1] * (1.0f / kPoints) * cur.rA.w * 0.5f};
-                    }
+                    xyA[k] = f32x2{cur.rA.x + cur.lA[2 * k] * iwA, cur.rA.y + cur.lA[2 * k + 1] * ihA};
                 }
 #pragma unroll
                 for (int k = 0; k < kB; ++k) {
                     const bool second = LT == 5 && k >= nB0;
-                    const f32x4 rc = second ? cur.rB1 : cur.rB0;
+                    const f32x2 rc = second ? cur.rB1 : cur.rB0;
                     atB[k] *= inv_sum;
-                    if (a.ref_dim == 2) {
-                        xyB[k] = f32x2{rc.x + cur.lB[2 * k] * (second ? iwB1 : iwB0), rc.y + cur.lB[2 * k + 1] * (second ? ihB1 : ihB0)};
-                    } else {
-                        xyB[k] = f32x2{rc.x + cur.lB[2 * k] * (1.0f / kPoints) * rc.z * 0.5f, rc.y + cur.lB[2 * k + 1] * (1.0f / kPoints) * rc.w * 0.5f};
-                    }
+                    xyB[k] = f32x2{rc.x + cur.lB[2 * k] * (second ? iwB1 : iwB0), rc.y + cur.lB[2 * k + 1] * (second ? ihB1 : ihB0)};
                 }
             } else {
 #pragma unroll
@@ -353,11 +372,13 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
             };
             // kAhead = how many steps ahead a fine point's rows are asked for; kLoose: no fences inside a step (two waves per SIMD have
             // 256 registers each: let the compiler overlap the coarse points' LDS round trips)
-            constexpr int kAhead = RW == 8 ? 2 : 1;
+            constexpr int kAhead = RW == 8 ? ((DBG & 16) ? 3 : (DBG & 32) ? 4 : (DBG & 64) ? 1 : 2) : 1;
             constexpr bool kLoose = RW == 8;
             Rows fine[kFirstB];
             fine[0] = from_plane(corner_addr(std::integral_constant<int, 0>{}));
-            if constexpr (kAhead == 2) fine[1] = from_plane(corner_addr(std::integral_constant<int, 1>{}));
+            if constexpr (kAhead >= 2) fine[1] = from_plane(corner_addr(std::integral_constant<int, 1>{}));
+            if constexpr (kAhead >= 3) fine[2] = from_plane(corner_addr(std::integral_constant<int, 2>{}));
+            if constexpr (kAhead >= 4) fine[3] = from_plane(corner_addr(std::integral_constant<int, 3>{}));
             auto step_fn = [&](auto I) {
                 constexpr int i = decltype(I)::value;
                 __builtin_amdgcn_sched_barrier(0);           // a step's addresses are formed in the step (registers)
@@ -403,7 +424,9 @@ struct ResVariant {
 #ifdef RDETR_DEV
     static inline int waves = 12;
     static inline int dbg = 0;
+    static inline bool tiled = true;
 #else
+    static constexpr bool tiled = true;
     static constexpr int waves = 12;
 #endif
 };
@@ -415,6 +438,7 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
                             uint16_t *out, hipStream_t stream)
 {
     if (L != 4 && L != 5) return RDETR_ERR_UNSUPPORTED;
+    if (FUSED && ref_dim != 2) return RDETR_ERR_UNSUPPORTED;           // 4-d reference points (decoder): the query-run kernel
     if ((long long)S * 64 >= (1ll << 31)) return RDETR_ERR_UNSUPPORTED;
     ResArgs a{};
     long long at = 0;
@@ -442,9 +466,22 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
     while (lr > L - 2 && ((long long)S - a.start[lr - 1]) * 64 <= budget) --lr;  // one or two resident levels (the kernel's LR)
     if (lr == L) return RDETR_ERR_UNSUPPORTED;                           // not even the coarsest level fits
     a.value = value; a.src_a = src_a; a.src_b = src_b; a.ref = ref; a.out = out;
-    a.ref_dim = ref_dim; a.S = S; a.Nq = Nq; a.B = B; a.ld_a = ld_a; a.ld_b = ld_b;
+    a.S = S; a.Nq = Nq; a.B = B; a.ld_a = ld_a; a.ld_b = ld_b;
     a.lr = lr; a.start_lr = a.start[lr]; a.res_bytes = (S - a.start[lr]) * 64;
     a.stage_base = (int)((kResBase + a.res_bytes + 127) / 128 * 128);
+    a.tiled = (Nq == S && ResVariant::tiled) ? 1 : 0;
+    a.runs = (Nq + kRQ - 1) / kRQ;
+    if (a.tiled) {
+        long long t = 0;
+        for (int l = 0; l < L; ++l) {
+            a.tpre[l] = (int)t;
+            a.tw[l] = (a.w[l] + 3) / 4;
+            a.inv_tw[l] = 1.0f / (float)a.tw[l];
+            t += (long long)a.tw[l] * ((a.h[l] + 3) / 4);
+        }
+        if (t >= (1ll << 21)) return RDETR_ERR_UNSUPPORTED;
+        a.runs = (int)t;
+    }
     const int lds = a.stage_base + stage;
     static int cus = 0;
     if (cus == 0) {
@@ -465,6 +502,9 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
     if (ResVariant::dbg && L == 4 && !FUSED && two) {
         if constexpr (!FUSED) {
             switch (ResVariant::dbg) {
+            case 16: return launch(msda_fwd_res_kernel<4, false, 8, 2, 16>, 8);
+            case 32: return launch(msda_fwd_res_kernel<4, false, 8, 2, 32>, 8);
+            case 64: return launch(msda_fwd_res_kernel<4, false, 8, 2, 64>, 8);
             case 1: return launch(msda_fwd_res_kernel<4, false, 12, 2, 1>, 12);
             case 2: return launch(msda_fwd_res_kernel<4, false, 12, 2, 2>, 12);
             case 3: return launch(msda_fwd_res_kernel<4, false, 12, 2, 3>, 12);
@@ -534,6 +574,7 @@ extern "C" int rdetr_msda_forward_fused_resident_bf16(const uint16_t *value, con
 }
 
 #ifdef RDETR_DEV
+extern "C" void rdetr_dev_set_res_tiled(int v) { rdetr::ResVariant::tiled = v != 0; }
 extern "C" void rdetr_dev_set_res_dbg(int v) { rdetr::ResVariant::dbg = v; }
 extern "C" void rdetr_dev_set_res_waves(int v) { rdetr::ResVariant::waves = (v == 8 || v == 16) ? v : 12; }
 #endif

@@ -39,24 +39,24 @@ def main():
                   f"differing elements {int((diff > 0).sum())} of {diff.numel()})  bit-identical: {torch.equal(out, ref)}", flush=True)
             variants = [("direct", 16), ("resident", 16), ("direct", 16), ("resident", 16)]
             if hasattr(devlib, "rdetr_dev_set_res_waves"):                                  # development library: waves per workgroup
-                variants = [("direct", 12), ("resident", 16), ("resident", 12), ("resident", 8), ("direct", 12), ("resident", 16), ("resident", 12), ("resident", 8)]
+                variants = [("direct", 12, 0), ("resident", 12, 0), ("resident", 12, 1), ("resident", 8, 0), ("resident", 8, 1), ("direct", 12, 0), ("resident", 12, 0), ("resident", 12, 1), ("resident", 8, 0), ("resident", 8, 1)]
 
             for v in variants:
                 algo, waves, sg = (v + (0,))[:3]
                 if hasattr(devlib, "rdetr_dev_set_res_waves"):
                     devlib.rdetr_dev_set_res_waves(waves)
-                if hasattr(devlib, "rdetr_dev_set_res_stagger"):
-                    devlib.rdetr_dev_set_res_stagger(sg)
+                if hasattr(devlib, "rdetr_dev_set_res_tiled"):
+                    devlib.rdetr_dev_set_res_tiled(sg)
                 f = lambda: fn(algo)
                 same = torch.equal(f().float(), ref) if algo == "resident" else True
                 for _ in range(2 * reps):
                     f()
                 t = bench._timed_launches(f, reps)
-                print(f"    {algo:9s} waves {waves:2d} stagger {sg} {t * 1e6:8.1f} us   bit-identical to direct: {same}", flush=True)
+                print(f"    {algo:9s} waves {waves:2d} tiled {sg} {t * 1e6:8.1f} us   bit-identical to direct: {same}", flush=True)
             if hasattr(devlib, "rdetr_dev_set_res_waves"):
                 devlib.rdetr_dev_set_res_waves(12)
-                if hasattr(devlib, "rdetr_dev_set_res_stagger"):
-                    devlib.rdetr_dev_set_res_stagger(0)
+                if hasattr(devlib, "rdetr_dev_set_res_tiled"):
+                    devlib.rdetr_dev_set_res_tiled(1)
         del value, vh, loc, attn, fi
         torch.cuda.empty_cache()
 

@@ -26,7 +26,13 @@ def main():
     value, shapes, start, loc, attn, S, L = bench.encoder_kernel_inputs(B, dev, torch.bfloat16)
     vh = value.permute(0, 2, 1, 3).contiguous()
     fn = lambda: rd.ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="resident")
-    for dbg in (0, 1, 2, 3, 4, 8, 9, 7, 11, 12, 15, 0):
+    order = (0, 1, 2, 3, 4, 8, 9, 7, 11, 12, 15, 0)
+    if len(sys.argv) > 2 and sys.argv[2] == "ahead":
+        NAMES.update({64: "8 waves, fine rows 1 step ahead", 16: "8 waves, 3 steps ahead", 32: "8 waves, 4 steps ahead"})
+        lib.rdetr_dev_set_res_waves(8)
+        NAMES[0] = "8 waves, 2 steps ahead"
+        order = (0, 64, 16, 32, 0, 64, 16, 32)
+    for dbg in order:
         lib.rdetr_dev_set_res_dbg(dbg)
         for _ in range(80):
             fn()

@@ -60,7 +60,7 @@ HBM_PEAK = 8.0e12           # B/s, MI355X spec (MI355X_MICROARCH.md)
 SETUP_REPLAYS = 12              # untimed replays before the contract's W warm-up steps (clock ramp after the idle capture phase)
 KERNEL_REPS = 50                # timed launches of the roofline kernel; 2 x KERNEL_REPS untimed launches right before them
 METRIC = "images/sec @ 800\u00d71333, 300 queries, R50 4-level; achieved HBM GB/s"      # BASELINE.json, verbatim
-ROOFLINE_KERNEL = ("msda_fwd_qrun_kernel<bf16, L=%d> on the head-major value [B,H,S,D] the module path's value projection writes "
+ROOFLINE_KERNEL = ("%s on the head-major value [B,H,S,D] the module path's value projection writes "
                    "(encoder shape, B=%d; operator form with materialised locations / weights = SURVEY 8d's bytes)")
 # padded pyramid per reference config; `batch` = images per GPU
 CONFIGS = {
@@ -150,7 +150,7 @@ def encoder_kernel_inputs(B, dev, dtype, level_shapes=R50_SHAPES):
     return value, shapes.to(dev), start.to(dev), loc, attn, S, L
 
 
-def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SHAPES, busy=None):
+def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SHAPES, busy=None, algo=None):
     """Average duration of the dominant kernel from device events recorded on the stream it is launched on.
     layout None = the one the stack runs the kernel in: head-major [B,H,S,D] for bf16 (written by the value projection's
     epilogue, relation_detr_amd/ms_deform_attn.py), the reference operator's [B,S,H,D] for fp32.
@@ -166,6 +166,8 @@ def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SH
     if layout == "bhsd":
         value = value.permute(0, 2, 1, 3).contiguous()
     kw = {"value_layout": layout} if dtype == torch.bfloat16 else {}
+    if algo is not None:                                    # name the kernel (default: what the operator picks itself)
+        kw["algo"] = algo
     for _ in range(3):
         rd.ms_deform_attn_forward(value, shapes, start, loc, attn, 64, **kw)
     torch.cuda.synchronize()
@@ -180,6 +182,16 @@ def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SH
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3, S, L
+
+
+def gather_kernel_name(B, Nq, L, fused):
+    """Which kernel the bf16 operator on a head-major value launches at this shape (relation_detr_amd/ops.py::_resident_pays)."""
+    import relation_detr_amd as rd
+    if rd.ops._resident_pays(B, Nq, L):
+        return ("msda_fwd_res_kernel<L=%d, FUSED=%s> (csrc/msda_res.hip: persistent workgroups, the coarse levels of an (image, head) "
+                "plane resident in LDS, fine levels through the buffer descriptor)" % (L, "true" if fused else "false"))
+    return "msda_fwd_qrun_kernel<bf16, L=%d, FUSED=%s> (csrc/msda_fwd.hip: query-run kernel, every corner row through the buffer descriptor)" % (
+        L, "true" if fused else "false")
 
 
 def _timed_launches(fn, reps, busy=None):
@@ -260,7 +272,7 @@ def pmc_traffic(dtype_name, B, config="r50"):
     taken at; `traffic` is null when no pass of the current default kernel is on file.
     traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE doubled as the guide prescribes for gfx950."""
     name, batch = ("pmc_msda_fwd_B4_encoder.json", 4) if config == "r50" else ("pmc_msda_fwd_B2_focalnet.json", 2)
-    path = next((q for q in (os.path.join(ROOT, "profiles", r, name) for r in ("r03", "r02")) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, name) for r in ("r04", "r03", "r02")) if os.path.exists(q)), None)
     if B != batch or path is None:
         return {"traffic": None}
     rec = json.load(open(path))
@@ -603,16 +615,17 @@ def main():
     t_kernel_cold = time_encoder_kernel(B, dev, dtype, reps=20, level_shapes=cfg["shapes"], busy=None)[0]     # round-2 protocol: 3 warm-up + 20
     t_kernel, S, L = time_encoder_kernel(B, dev, dtype, reps=KERNEL_REPS, level_shapes=cfg["shapes"], busy=busy)
     t_kernel_bshd = time_encoder_kernel(B, dev, dtype, layout="bshd", level_shapes=cfg["shapes"], busy=busy)[0] if args.dtype == "bf16" else None
+    t_kernel_qrun = time_encoder_kernel(B, dev, dtype, level_shapes=cfg["shapes"], busy=busy, algo="direct")[0] if args.dtype == "bf16" else None
     t_kernel_fp32 = time_encoder_kernel(B, dev, torch.float32, level_shapes=cfg["shapes"], busy=busy)[0] if args.dtype == "bf16" else None
     in_stack = relation = sweep_ms = None
     if args.dtype == "bf16" and rank == 0:
         note("in-stack gather instantiation, relation kernels")
-        in_stack = {"kernel": "msda_fwd_qrun_kernel<bf16, L=%d, FUSED=true> on the head-major value (what the timed region launches for the "
-                              "encoder's MSDA: raw bf16 offsets / logits + fp32 reference points in, softmax and location arithmetic "
-                              "inside the kernel), encoder shape, isolated" % L}
+        in_stack = {"kernel": "fused-producer form on the head-major value (what the timed region launches for the encoder's MSDA: raw bf16 "
+                              "offsets / logits + fp32 reference points in, softmax and location arithmetic inside the kernel), encoder "
+                              "shape, isolated; per batch size the kernel the operator picks: see `kernel` of each entry"}
         for bb in sorted({B, max(1, B // max(1, nstreams))}, reverse=True):      # the whole batch, and one image group of it
             t_f, moved, survey = time_in_stack_kernel(bb, dev, level_shapes=cfg["shapes"], busy=busy)
-            in_stack["B%d" % bb] = {"kernel_ms": t_f * 1e3, "bytes_moved": moved, "frac_of_bytes_moved": moved / t_f / HBM_PEAK,
+            in_stack["B%d" % bb] = {"kernel": gather_kernel_name(bb, S, L, True), "kernel_ms": t_f * 1e3, "bytes_moved": moved, "frac_of_bytes_moved": moved / t_f / HBM_PEAK,
                                     "survey_8d_bytes": survey, "frac_of_survey_bytes": survey / t_f / HBM_PEAK}
         t_bias, bias_bytes, t_attn = time_relation_kernels(B, dev, N=Nq, busy=busy)
         relation = {"bias_materialised": {"kernel": "relation_bias_kernel via rdetr_relation_bias_ws_f32, B=%d, N=%d "
@@ -750,7 +763,7 @@ def main():
                        "launch": launch, "streams": nstreams,
                        "gemm_tuning": tuned,
                        "parallelism": f"image-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": (ROOFLINE_KERNEL % (L, B)) if args.dtype == "bf16" else "msda_fwd_qrun_kernel<float, L=%d> (encoder shape, B=%d)" % (L, B),
+            "roofline": {"bound": "hbm", "kernel": (ROOFLINE_KERNEL % (gather_kernel_name(B, S, L, False), B)) if args.dtype == "bf16" else "msda_fwd_qrun_kernel<float, L=%d> (encoder shape, B=%d)" % (L, B),
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / t_kernel / HBM_PEAK, **pmc_traffic(args.dtype, B, args.config),
                          "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3,
@@ -760,6 +773,9 @@ def main():
                                           "20 timed launches after a host synchronisation (round-2 protocol: measures the clock ramp)"
                                           % (KERNEL_REPS, 2 * KERNEL_REPS),
                          "kernel_preheat_launches": 2 * KERNEL_REPS,
+                         "query_run_kernel_ms": None if t_kernel_qrun is None else t_kernel_qrun * 1e3,
+                         "query_run_kernel_note": "the same operator on the same inputs through msda_fwd_qrun_kernel (algo='direct': every corner row "
+                                                  "through the texture path, the kernel of rounds 1-3), same timing protocol",
                          "in_stack": in_stack, "relation": relation,
                          "lds_sourced_alternative": None if sweep_ms is None else {
                              "kernel": "msda_fwd_sweep_kernel (csrc/msda_sweep.hip, opt-in algo='sweep'), same inputs", "kernel_ms": sweep_ms,

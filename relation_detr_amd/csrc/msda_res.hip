@@ -352,10 +352,29 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
             constexpr int kCoarse = LP - kFirstB;            // 8 or 12
             Inputs nxt;
             auto consume = [&](const Rows &rw, const u32x2 wq) {
-                if constexpr ((DBG & 8) != 0) {
+                if constexpr ((DBG & 128) != 0) {            // the matrix-core steps without the v_perm re-pairing (upper bound of a transposing read)
+                    const s16x4 am = __builtin_bit_cast(s16x4, wq);
+                    const unsigned t0[4] = {rw.r00.x, rw.r00.y, rw.r00.z, rw.r00.w}, t1[4] = {rw.r01.x, rw.r01.y, rw.r01.z, rw.r01.w};
+                    const unsigned b0[4] = {rw.r10.x, rw.r10.y, rw.r10.z, rw.r10.w}, b1[4] = {rw.r11.x, rw.r11.y, rw.r11.z, rw.r11.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        accm[2 * j] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(am, __builtin_bit_cast(s16x4, u32x2{t0[j], b0[j]}), accm[2 * j], 0, 0, 0);
+                        accm[2 * j + 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(am, __builtin_bit_cast(s16x4, u32x2{t1[j], b1[j]}), accm[2 * j + 1], 0, 0, 0);
+                    }
+                } else if constexpr ((DBG & 8) != 0) {
                     accm[0].x += __builtin_bit_cast(float, rw.r00.x ^ rw.r01.y ^ rw.r10.z ^ rw.r11.w ^ wq.x);
                 } else {
                     mfma_point(rw.r00, rw.r01, rw.r10, rw.r11, wq, accm);
+                }
+            };
+            auto consume_noperm = [&](const Rows &rw, const u32x2 wq) {
+                const s16x4 am = __builtin_bit_cast(s16x4, wq);
+                const unsigned t0[4] = {rw.r00.x, rw.r00.y, rw.r00.z, rw.r00.w}, t1[4] = {rw.r01.x, rw.r01.y, rw.r01.z, rw.r01.w};
+                const unsigned b0[4] = {rw.r10.x, rw.r10.y, rw.r10.z, rw.r10.w}, b1[4] = {rw.r11.x, rw.r11.y, rw.r11.z, rw.r11.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    accm[2 * j] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(am, __builtin_bit_cast(s16x4, u32x2{t0[j], b0[j]}), accm[2 * j], 0, 0, 0);
+                    accm[2 * j + 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(am, __builtin_bit_cast(s16x4, u32x2{t1[j], b1[j]}), accm[2 * j + 1], 0, 0, 0);
                 }
             };
             auto coarse = [&](auto PT) {
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
                 const u32x2 wq = weights_of(pt);
                 if constexpr (pt >= lr4) {
                     const Rows b = from_lds(ad);
-                    consume(b, wq);
+                    if constexpr ((DBG & 256) != 0) consume_noperm(b, wq); else consume(b, wq);
                 } else {
                     const Rows b = from_plane(ad);
                     consume(b, wq);
@@ -374,6 +393,37 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
             // 256 registers each: let the compiler overlap the coarse points' LDS round trips)
             constexpr int kAhead = RW == 8 ? ((DBG & 16) ? 3 : (DBG & 32) ? 4 : (DBG & 64) ? 1 : 2) : 1;
             constexpr bool kLoose = RW == 8;
+            if constexpr (RW == 8 && LT == 4 && LR == 2 && (DBG & 512) != 0) {
+                // explicit pipeline (two waves per SIMD, 256 registers): all weights up front, fine rows two steps ahead, the coarse
+                // rows (LDS) one step ahead -- no instruction waits on a round trip it has just started
+                u32x2 wq[LP];
+#pragma unroll
+                for (int pt = 0; pt < LP; ++pt) wq[pt] = weights_of(pt);
+                Rows fine[kFirstB], cz[kCoarse];
+                fine[0] = from_plane(corner_addr(std::integral_constant<int, 0>{}));
+                fine[1] = from_plane(corner_addr(std::integral_constant<int, 1>{}));
+                cz[0] = from_lds(corner_addr(std::integral_constant<int, kFirstB>{}));
+                auto pstep = [&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (i + 2 < kFirstB) fine[i + 2] = from_plane(corner_addr(std::integral_constant<int, i + 2>{}));
+                    if constexpr (i + 3 == kFirstB) {
+                        if (r + step < runs) load_inputs(r + step, nxt);
+                    }
+                    if constexpr (i + 1 < kCoarse) cz[i + 1] = from_lds(corner_addr(std::integral_constant<int, kFirstB + i + 1>{}));
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(cz[i], wq[kFirstB + i]);
+                    consume(fine[i], wq[i]);
+                };
+                pstep(std::integral_constant<int, 0>{});
+                pstep(std::integral_constant<int, 1>{});
+                pstep(std::integral_constant<int, 2>{});
+                pstep(std::integral_constant<int, 3>{});
+                pstep(std::integral_constant<int, 4>{});
+                pstep(std::integral_constant<int, 5>{});
+                pstep(std::integral_constant<int, 6>{});
+                pstep(std::integral_constant<int, 7>{});
+            } else {
             Rows fine[kFirstB];
             fine[0] = from_plane(corner_addr(std::integral_constant<int, 0>{}));
             if constexpr (kAhead >= 2) fine[1] = from_plane(corner_addr(std::integral_constant<int, 1>{}));
@@ -406,6 +456,7 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
             step_fn(std::integral_constant<int, 5>{});
             step_fn(std::integral_constant<int, 6>{});
             step_fn(std::integral_constant<int, 7>{});
+            }
             static_assert(kFirstB == 8, "eight steps");
 
             float res[8];
@@ -502,6 +553,9 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
     if (ResVariant::dbg && L == 4 && !FUSED && two) {
         if constexpr (!FUSED) {
             switch (ResVariant::dbg) {
+            case 512: return launch(msda_fwd_res_kernel<4, false, 8, 2, 512>, 8);
+            case 128: return launch(msda_fwd_res_kernel<4, false, 12, 2, 128>, 12);
+            case 256: return launch(msda_fwd_res_kernel<4, false, 12, 2, 256>, 12);
             case 16: return launch(msda_fwd_res_kernel<4, false, 8, 2, 16>, 8);
             case 32: return launch(msda_fwd_res_kernel<4, false, 8, 2, 32>, 8);
             case 64: return launch(msda_fwd_res_kernel<4, false, 8, 2, 64>, 8);

@@ -29,7 +29,7 @@ find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -dele
 unset RDETR_BENCH_STREAMS
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   tag=$(echo $grp | tr ' ' '+')
-  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -- python3 tools/profile_win.py bhsd 6 direct > $O/pmc_$tag.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -- python3 tools/profile_win.py bhsd 6 auto > $O/pmc_$tag.log 2>&1
 done
 find $O -name "*agent_info.csv" -delete
 du -sh $O

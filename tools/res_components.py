@@ -27,6 +27,13 @@ def main():
     vh = value.permute(0, 2, 1, 3).contiguous()
     fn = lambda: rd.ops.ms_deform_attn_forward(vh, shapes, start, loc, attn, value_layout="bhsd", algo="resident")
     order = (0, 1, 2, 3, 4, 8, 9, 7, 11, 12, 15, 0)
+    if len(sys.argv) > 2 and sys.argv[2] == "noperm":
+        NAMES.update({128: "no v_perm re-pairing at all (wrong operands)", 256: "no v_perm re-pairing for the coarse (LDS) points"})
+        order = (0, 256, 128, 0, 256, 128, 0, 256, 128)
+    if len(sys.argv) > 2 and sys.argv[2] == "pipe":
+        NAMES.update({512: "8 waves, explicit pipeline (weights up front, coarse rows one step ahead)", 64: "8 waves, compiler's schedule, fine rows 1 step ahead"})
+        NAMES[0] = "12 waves (product)"
+        order = (0, 512, 64, 0, 512, 64, 0, 512, 64)
     if len(sys.argv) > 2 and sys.argv[2] == "ahead":
         NAMES.update({64: "8 waves, fine rows 1 step ahead", 16: "8 waves, 3 steps ahead", 32: "8 waves, 4 steps ahead"})
         lib.rdetr_dev_set_res_waves(8)

@@ -49,6 +49,8 @@ struct ResArgs {
     int stage_base;                              // LDS offset of the staging area (multiple of 128)
     // Nq == S (the queries are the pyramid's pixels): a run is a 4 x 4 TILE of one level instead of 16 consecutive pixels
     int tiled, runs;                             // runs = tiles of all levels | ceil(Nq / 16)
+    int plane_major;                             // development A/B: 0 = plane p on XCD p % 8
+    int max_teams;                               // planes of an XCD in flight at a time
     int tpre[5], tw[5];                          // tiles before level l, tiles per tile row
     float inv_tw[5];
 };
@@ -101,10 +103,17 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
     const int nx = (int)gridDim.x >> 3;                              // workgroups per XCD
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
     const int planes = a.B * kHeads;
-    const int Jx = (planes - xcd + 7) >> 3;                          // planes p = xcd + 8 j of this XCD
+    // An XCD's planes are CONSECUTIVE: planes = 8 B is a multiple of 8, so XCD x serves planes x B .. x B + B - 1 -- neighbouring
+    // heads of one image.  The query-side rows hold a query's 8 heads side by side (per head 128 B of locations + 64 B of weights;
+    // fused form 64 B of raw offsets + 32 B of logits at L = 4): with head m on XCD m every L2 fetched its neighbours' heads' halves
+    // of each 128-byte line as well; the planes of one XCD now sweep the same queries at the same pace and share those lines.
+    const int Jx = planes >> 3;
     if (Jx <= 0) return;
-    const int G = nx / Jx > 0 ? nx / Jx : 1;                         // workgroups per plane
-    const int teams = Jx < nx ? Jx : nx;
+    // a.max_teams planes of an XCD are in flight at a time (their fine levels' bands share its 4-MiB L2 with the query-side streams);
+    // a team of G workgroups takes planes team, team + teams, ... one after the other
+    const int want = Jx < a.max_teams ? Jx : a.max_teams;
+    const int teams = want < nx ? want : nx;
+    const int G = nx / teams;                                        // workgroups per plane
     const int team = slot / G, g = slot - team * G;
     if (team >= teams) return;                                       // nx not a multiple of Jx: the remainder idles
 
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(RW *kWave) void msda_fwd_res_kernel(const ResArgs a
     const int runs = a.runs;
 
     for (int j = team; j < Jx; j += teams) {
-        const int p = xcd + 8 * j, b = p >> 3, m = p & 7;
+        const int p = (a.plane_major ? xcd * Jx + j : xcd + 8 * j), b = p >> 3, m = p & 7;
         const uint16_t *plane = a.value + ((size_t)b * kHeads + m) * (size_t)a.S * kHeadDim;
         __syncthreads();                                             // the previous plane's readers are done
         if (tid < 4) *reinterpret_cast<u32x4 *>(smem + tid * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -476,8 +485,12 @@ struct ResVariant {
     static inline int waves = 12;
     static inline int dbg = 0;
     static inline bool tiled = true;
+    static inline bool plane_major = true;
+    static inline int max_teams = 0;                 // 0 = the product's choice
 #else
+    static constexpr int max_teams = 0;
     static constexpr bool tiled = true;
+    static constexpr bool plane_major = true;
     static constexpr int waves = 12;
 #endif
 };
@@ -520,6 +533,11 @@ static int msda_res_forward(const uint16_t *value, const int64_t *shapes, const 
     a.S = S; a.Nq = Nq; a.B = B; a.ld_a = ld_a; a.ld_b = ld_b;
     a.lr = lr; a.start_lr = a.start[lr]; a.res_bytes = (S - a.start[lr]) * 64;
     a.stage_base = (int)((kResBase + a.res_bytes + 127) / 128 * 128);
+    a.plane_major = ResVariant::plane_major ? 1 : 0;
+    // operator form: two planes of an XCD in flight (a head PAIR: the weights' 128-byte lines are shared) -- 2.56 M -> 1.76 M L2 -> fabric
+    // read requests at B = 4 against all four (225 MB for 183 MB of distinct bytes), same time; fused form: all of them (its raw
+    // logits share a line between FOUR heads; 94-97 us against 97-103) -- profiles/r04/ab_res_planes_in_flight.txt
+    a.max_teams = ResVariant::max_teams > 0 ? ResVariant::max_teams : (FUSED ? (1 << 20) : 2);
     a.tiled = (Nq == S && ResVariant::tiled) ? 1 : 0;
     a.runs = (Nq + kRQ - 1) / kRQ;
     if (a.tiled) {
@@ -628,6 +646,8 @@ extern "C" int rdetr_msda_forward_fused_resident_bf16(const uint16_t *value, con
 }
 
 #ifdef RDETR_DEV
+extern "C" void rdetr_dev_set_res_max_teams(int v) { rdetr::ResVariant::max_teams = v;                 // 0 = the product's choice }
+extern "C" void rdetr_dev_set_res_plane_major(int v) { rdetr::ResVariant::plane_major = v != 0; }
 extern "C" void rdetr_dev_set_res_tiled(int v) { rdetr::ResVariant::tiled = v != 0; }
 extern "C" void rdetr_dev_set_res_dbg(int v) { rdetr::ResVariant::dbg = v; }
 extern "C" void rdetr_dev_set_res_waves(int v) { rdetr::ResVariant::waves = (v == 8 || v == 16) ? v : 12; }

@@ -39,24 +39,24 @@ def main():
                   f"differing elements {int((diff > 0).sum())} of {diff.numel()})  bit-identical: {torch.equal(out, ref)}", flush=True)
             variants = [("direct", 16), ("resident", 16), ("direct", 16), ("resident", 16)]
             if hasattr(devlib, "rdetr_dev_set_res_waves"):                                  # development library: waves per workgroup
-                variants = [("direct", 12, 0), ("resident", 12, 0), ("resident", 12, 1), ("resident", 8, 0), ("resident", 8, 1), ("direct", 12, 0), ("resident", 12, 0), ("resident", 12, 1), ("resident", 8, 0), ("resident", 8, 1)]
+                variants = [("direct", 12, 0), ("resident", 12, 0), ("resident", 12, 2), ("resident", 12, 1), ("direct", 12, 0), ("resident", 12, 0), ("resident", 12, 2), ("resident", 12, 1), ("resident", 12, 0), ("resident", 12, 2), ("resident", 12, 1)]
 
             for v in variants:
                 algo, waves, sg = (v + (0,))[:3]
                 if hasattr(devlib, "rdetr_dev_set_res_waves"):
                     devlib.rdetr_dev_set_res_waves(waves)
-                if hasattr(devlib, "rdetr_dev_set_res_tiled"):
-                    devlib.rdetr_dev_set_res_tiled(sg)
+                if hasattr(devlib, "rdetr_dev_set_res_max_teams"):
+                    devlib.rdetr_dev_set_res_max_teams(sg)
                 f = lambda: fn(algo)
                 same = torch.equal(f().float(), ref) if algo == "resident" else True
                 for _ in range(2 * reps):
                     f()
                 t = bench._timed_launches(f, reps)
-                print(f"    {algo:9s} waves {waves:2d} tiled {sg} {t * 1e6:8.1f} us   bit-identical to direct: {same}", flush=True)
+                print(f"    {algo:9s} waves {waves:2d} planes in flight per XCD (0 = all) {sg} {t * 1e6:8.1f} us   bit-identical to direct: {same}", flush=True)
             if hasattr(devlib, "rdetr_dev_set_res_waves"):
                 devlib.rdetr_dev_set_res_waves(12)
-                if hasattr(devlib, "rdetr_dev_set_res_tiled"):
-                    devlib.rdetr_dev_set_res_tiled(1)
+                if hasattr(devlib, "rdetr_dev_set_res_max_teams"):
+                    devlib.rdetr_dev_set_res_max_teams(0)
         del value, vh, loc, attn, fi
         torch.cuda.empty_cache()
 

@@ -646,7 +646,7 @@ extern "C" int rdetr_msda_forward_fused_resident_bf16(const uint16_t *value, con
 }
 
 #ifdef RDETR_DEV
-extern "C" void rdetr_dev_set_res_max_teams(int v) { rdetr::ResVariant::max_teams = v;                 // 0 = the product's choice }
+extern "C" void rdetr_dev_set_res_max_teams(int v) { rdetr::ResVariant::max_teams = v; }           // 0 = the product's choice
 extern "C" void rdetr_dev_set_res_plane_major(int v) { rdetr::ResVariant::plane_major = v != 0; }
 extern "C" void rdetr_dev_set_res_tiled(int v) { rdetr::ResVariant::tiled = v != 0; }
 extern "C" void rdetr_dev_set_res_dbg(int v) { rdetr::ResVariant::dbg = v; }

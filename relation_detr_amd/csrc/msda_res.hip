@@ -1,25 +1,35 @@
 // Multi-scale deformable attention, forward, bf16, head-major value [B,H,S,D] -- "resident coarse levels" kernel for gfx950.
 //
-// Same operator as msda_fwd.hip (reference: ms_deform_im2col_cuda.cuh:226-288) and the same per-query arithmetic in the same
-// order, so the results are bit-identical to msda_fwd_qrun_kernel's.  What changes is WHERE the corner rows come from.
+// Same operator as msda_fwd.hip (reference: ms_deform_im2col_cuda.cuh:226-288) and the same arithmetic per sampling point; the points
+// of a query are accumulated in another order, so results agree with msda_fwd_qrun_kernel's to fp32 re-association (the last bit of
+// a bf16 output now and then: 4e-5 of the outputs at the R50 shape).  What changes is WHERE the corner rows come from.
 //
 // The query-run kernel brings every corner row through the texture path, whose addresser retires one 64-lane x 16-byte
-// instruction per ~16.5 clocks and CU: 64 such gathers per wave and run of 16 queries at 4 levels -- the kernel's ceiling
+// instruction per ~17 clocks and CU: 64 such gathers per wave and run of 16 queries at 4 levels -- that kernel's ceiling
 // (DESIGN 4.1).  But the levels are not alike: at the R50 encoder shape levels 2 and 3 together are 1,323 pixels = 85 KB of
 // an (image, head) plane and receive HALF of all samples.  So:
-//   * one persistent 16-wave workgroup per CU serves ONE (image, head) plane (several, one after the other, when there are more
-//     planes than the XCD has workgroups) and keeps that plane's coarse levels lr .. L-1 -- as many as fit beside the staging
-//     area -- RESIDENT in LDS: one contiguous copy, since the levels are packed along S;
+//   * one persistent 12-wave workgroup per CU serves ONE (image, head) plane at a time and keeps that plane's coarse levels
+//     LR .. L-1 -- the last one or two, as many as fit beside the staging area -- RESIDENT in LDS: one contiguous copy, since the
+//     levels are packed along S;
 //   * a sample on a resident level reads its corner rows with ds_read_b128 from that copy (a corner outside the level reads a
 //     64-byte row of zeros at LDS offset 0: the zero padding of .cuh:44-67), a sample on a fine level goes through the buffer
 //     descriptor as before.  No windows, no halo, no flagged samples: a resident level is resident as a whole.  The texture path
-//     carries half the instructions, the LDS (4x its rate) the other half, and the vector ALU -- unchanged: set-up, v_perm
-//     re-pairing, MFMA issue -- becomes the limiter;
-//   * workgroups with the same blockIdx % 8 share an XCD (private L2): plane p lives on XCD p % 8, its G workgroups sweep the
-//     queries together (run r of workgroup g, wave w: r = k * 16 G + 16 g + w);
-//   * staging (corner offsets + split weights per (point, query), private to a wave) is done in two halves -- points 0..7, then
-//     8..L*P-1, every lane preparing two (three) consecutive points of each -- so that 16 waves' staging (64-96 KiB) and the
-//     resident levels fit the CU's 160 KB.
+//     and the LDS are independent units (tools/microbench/ta_lds_concurrency.hip: mixed traffic takes the maximum, not the sum);
+//   * a lane prepares two points of levels 0 / 1 and two (three) coarse points; the four corner OFFSETS of a point stay in its
+//     registers and reach the query's other three lanes inside the address add (v_add_u32_dpp quad_perm: no LDS round trip, no
+//     extra instruction), only the split corner WEIGHTS -- the matrix-core A operand, which differs from lane to lane -- are
+//     staged in LDS (4 KiB per wave);
+//   * eight software-pipelined steps per run: ask for the plane rows of fine point i + 1, work off a coarse point from LDS, take
+//     in fine point i; the next run's inputs are asked for behind the run's last plane rows (loads return in order);
+//   * encoder shape (Nq == S): a run is a 4 x 4 TILE of one level instead of 16 consecutive pixels (a third fewer distinct rows
+//     per gather instruction: L1 -> L2 requests 10.6 M -> 6.6 M per launch);
+//   * an XCD (private L2) serves CONSECUTIVE planes -- neighbouring heads of one image, which share the 128-byte lines of the
+//     query-side rows -- with its workgroups split into teams, a team per plane in flight, the workgroups of a team sweeping the
+//     plane's runs together (run r of workgroup g, wave w: r = k * 12 G + 12 g + w).
+// Measured at BASELINE.json configs[1] (B = 4, S = Nq = 22,323): 91-96 us against the query-run kernel's 106-110 (0.30 vs 0.26 of
+// the HBM roofline on SURVEY 8d's bytes); the vector ALU's share is ~56 us, the texture path's ~46, the query-side streams' ~41
+// (profiles/r04/components_msda_res.txt, pmc_msda_res_B4_encoder.txt).  Tried and not kept: 8 and 16 waves, deeper pipelines, a
+// paired-wave form (fine and coarse points in partner waves) -- profiles/r04/README.md.
 // The level table is a HOST argument here (the resident set is sized on the host); callers that only have the device tensors
 // use the query-run kernel.
 #include <cstdlib>
@@ -614,7 +624,7 @@ static int res_common_checks(const void *value, const int64_t *hs, const int64_t
     if (B == 0 || Nq == 0) return RDETR_OK;
     if (!value || !hs || !hl || !a || !b || !out || S == 0) return RDETR_ERR_INVALID_ARG;
     if (H != rdetr::kHeads || D != rdetr::kHeadDim || P != rdetr::kPoints) return RDETR_ERR_UNSUPPORTED;
-    return -1;                                                           // go on
+    return 1;                                                            // go on
 }
 
 extern "C" int rdetr_msda_forward_resident_bf16(const uint16_t *value, const int64_t *host_spatial_shapes,
@@ -623,7 +633,7 @@ extern "C" int rdetr_msda_forward_resident_bf16(const uint16_t *value, const int
                                                 uint16_t *out, void *stream)
 {
     const int st = res_common_checks(value, host_spatial_shapes, host_level_start_index, sampling_loc, attn_weight, out, B, S, H, D, L, Nq, P);
-    if (st != -1) return st;
+    if (st != 1) return st;
     return rdetr::msda_res_forward<false>(value, host_spatial_shapes, host_level_start_index, sampling_loc, attn_weight, nullptr, 0, B, S,
                                           L, Nq, 0, 0, out, static_cast<hipStream_t>(stream));
 }
@@ -635,7 +645,7 @@ extern "C" int rdetr_msda_forward_fused_resident_bf16(const uint16_t *value, con
                                                       int Nq, int P, uint16_t *out, void *stream)
 {
     const int st = res_common_checks(value, host_spatial_shapes, host_level_start_index, sampling_offsets, attn_logits, out, B, S, H, D, L, Nq, P);
-    if (st != -1) return st;
+    if (st != 1) return st;
     if (!reference_points || (ref_dim != 2 && ref_dim != 4)) return RDETR_ERR_INVALID_ARG;
     if (ld_offsets < 0 || ld_logits < 0 || (ld_offsets && ld_offsets < H * L * P * 2) || (ld_logits && ld_logits < H * L * P) ||
         ld_offsets % 2 != 0)

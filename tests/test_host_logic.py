@@ -53,6 +53,21 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.rdetr_msda_forward_sweep_bf16(one, 0, shapes, starts, one, one, 1, 8160, 8, 64, 4, 8160, 4, one, None) == -2    # head dim
     assert lib.rdetr_msda_forward_sweep_bf16(one, 0, shapes, starts, one, one, 1, 8160, 8, 32, 4, 900, 4, one, None) == -2     # Nq != S
     assert lib.rdetr_msda_forward_sweep_bf16(one, 0, shapes, starts, one, one, 1, 9000, 8, 32, 4, 9000, 4, one, None) == -2    # levels do not tile S
+    # ... and so do the resident-levels kernel's (csrc/msda_res.hip): shape refusals are RDETR_ERR_UNSUPPORTED (callers fall back)
+    res, resf = lib.rdetr_msda_forward_resident_bf16, lib.rdetr_msda_forward_fused_resident_bf16
+    assert res(None, shapes, starts, None, None, 1, 8160, 8, 32, 4, 8160, 4, None, None) == -1
+    assert res(None, shapes, starts, None, None, 0, 8160, 8, 32, 4, 8160, 4, None, None) == 0
+    assert res(one, shapes, starts, one, one, 1, 8160, 8, 64, 4, 8160, 4, one, None) == -2                  # head dim
+    assert res(one, shapes, starts, one, one, 1, 9000, 8, 32, 4, 9000, 4, one, None) == -2                  # levels do not tile S
+    assert res(one, shapes, starts, one, one, 1, 8064, 8, 32, 3, 8064, 4, one, None) == -2                  # three levels
+    assert res(one, shapes, starts, ctypes.c_void_p(8), one, 1, 8160, 8, 32, 4, 8160, 4, one, None) == -2   # locations not 16-byte aligned
+    big = (ctypes.c_int64 * 8)(64, 64, 56, 56, 52, 52, 48, 48)
+    bigs = (ctypes.c_int64 * 4)(0, 4096, 7232, 9936)
+    assert res(one, big, bigs, one, one, 1, 12240, 8, 32, 4, 12240, 4, one, None) == -2                     # coarsest level (147 KB) does not fit the LDS
+    assert resf(one, shapes, starts, one, 0, one, 0, None, 2, 1, 8160, 8, 32, 4, 8160, 4, one, None) == -1  # no reference points
+    assert resf(one, shapes, starts, one, 0, one, 0, one, 3, 1, 8160, 8, 32, 4, 8160, 4, one, None) == -1   # ref_dim
+    assert resf(one, shapes, starts, one, 0, one, 0, one, 4, 1, 8160, 8, 32, 4, 8160, 4, one, None) == -2   # 4-d reference points: the query-run kernel's
+    assert resf(one, shapes, starts, one, 100, one, 0, one, 2, 1, 8160, 8, 32, 4, 8160, 4, one, None) == -1  # row stride below a row
 
 
 def test_msda_module_contract(golden):

@@ -184,10 +184,10 @@ def time_encoder_kernel(B, dev, dtype, reps=50, layout=None, level_shapes=R50_SH
     return e0.elapsed_time(e1) / reps * 1e-3, S, L
 
 
-def gather_kernel_name(B, Nq, L, fused):
+def gather_kernel_name(B, Nq, L, fused, level_shapes=None):
     """Which kernel the bf16 operator on a head-major value launches at this shape (relation_detr_amd/ops.py::_resident_pays)."""
     import relation_detr_amd as rd
-    if rd.ops._resident_pays(B, Nq, L):
+    if rd.ops._resident_pays(B, Nq, L, level_shapes):
         return ("msda_fwd_res_kernel<L=%d, FUSED=%s> (csrc/msda_res.hip: persistent workgroups, the coarse levels of an (image, head) "
                 "plane resident in LDS, fine levels through the buffer descriptor)" % (L, "true" if fused else "false"))
     return "msda_fwd_qrun_kernel<bf16, L=%d, FUSED=%s> (csrc/msda_fwd.hip: query-run kernel, every corner row through the buffer descriptor)" % (
@@ -625,7 +625,7 @@ def main():
                               "shape, isolated; per batch size the kernel the operator picks: see `kernel` of each entry"}
         for bb in sorted({B, max(1, B // max(1, nstreams))}, reverse=True):      # the whole batch, and one image group of it
             t_f, moved, survey = time_in_stack_kernel(bb, dev, level_shapes=cfg["shapes"], busy=busy)
-            in_stack["B%d" % bb] = {"kernel": gather_kernel_name(bb, S, L, True), "kernel_ms": t_f * 1e3, "bytes_moved": moved, "frac_of_bytes_moved": moved / t_f / HBM_PEAK,
+            in_stack["B%d" % bb] = {"kernel": gather_kernel_name(bb, S, L, True, cfg["shapes"]), "kernel_ms": t_f * 1e3, "bytes_moved": moved, "frac_of_bytes_moved": moved / t_f / HBM_PEAK,
                                     "survey_8d_bytes": survey, "frac_of_survey_bytes": survey / t_f / HBM_PEAK}
         t_bias, bias_bytes, t_attn = time_relation_kernels(B, dev, N=Nq, busy=busy)
         relation = {"bias_materialised": {"kernel": "relation_bias_kernel via rdetr_relation_bias_ws_f32, B=%d, N=%d "
@@ -763,7 +763,7 @@ def main():
                        "launch": launch, "streams": nstreams,
                        "gemm_tuning": tuned,
                        "parallelism": f"image-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": (ROOFLINE_KERNEL % (gather_kernel_name(B, S, L, False), B)) if args.dtype == "bf16" else "msda_fwd_qrun_kernel<float, L=%d> (encoder shape, B=%d)" % (L, B),
+            "roofline": {"bound": "hbm", "kernel": (ROOFLINE_KERNEL % (gather_kernel_name(B, S, L, False, cfg["shapes"]), B)) if args.dtype == "bf16" else "msda_fwd_qrun_kernel<float, L=%d> (encoder shape, B=%d)" % (L, B),
                          "achieved": alg / t_kernel / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / t_kernel / HBM_PEAK, **pmc_traffic(args.dtype, B, args.config),
                          "algorithmic_bytes": alg, "kernel_ms": t_kernel * 1e3,

@@ -145,10 +145,16 @@ def _msda_algo(algo: str, spatial_shapes, level_start_index, num_value: int) -> 
     return MSDA_AUTO_PACKED if ok else MSDA_DIRECT
 
 
-def _resident_pays(B: int, Nq: int, L: int) -> bool:
+def _resident_pays(B: int, Nq: int, L: int, level_shapes=None) -> bool:
     """'auto' on a head-major bf16 value: the resident-levels kernel (csrc/msda_res.hip: one persistent workgroup per CU) where it
-    was measured faster than the query-run kernel -- four levels and enough runs of 16 queries to feed 256 workgroups."""
-    return L == 4 and B * Nq >= 16384
+    was measured faster than the query-run kernel -- four levels, the last TWO of them (half of all samples) fitting the CU's LDS
+    beside the staging area, and enough runs of 16 queries to feed 256 workgroups."""
+    if L != 4 or B * Nq < 16384:
+        return False
+    if level_shapes is None:
+        return True
+    coarse = sum(int(h) * int(w) for h, w in level_shapes[2:]) * 64          # bytes of levels 2 and 3 of one (image, head) plane
+    return coarse <= 160 * 1024 - 128 - 12 * 4096 - 128                       # msda_res.hip: zero row + 12 waves' staging + alignment
 
 
 def _value_dims(value: torch.Tensor, layout: str):
@@ -195,7 +201,7 @@ def ms_deform_attn_forward(value: torch.Tensor, spatial_shapes: torch.Tensor, le
                                                out.data_ptr(), _stream_ptr(value))
         _lib.check(st, "rdetr_msda_forward_sweep_bf16")
         return out
-    if value.dtype == torch.bfloat16 and value_layout == "bhsd" and (algo == "resident" or (algo == "auto" and _resident_pays(B, Nq, L))):
+    if value.dtype == torch.bfloat16 and value_layout == "bhsd" and (algo == "resident" or (algo == "auto" and _resident_pays(B, Nq, L, host_levels(spatial_shapes, level_start_index)[0]))):
         # persistent workgroups with the coarse levels resident in LDS (csrc/msda_res.hip): large query counts on the head-major
         # layout; anything it does not cover comes back as RDETR_ERR_UNSUPPORTED and runs on the query-run kernel below
         hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
@@ -323,7 +329,7 @@ def ms_deform_attn_forward_fused(value: torch.Tensor, spatial_shapes: torch.Tens
         mask_ptr = mask_u8.data_ptr()
     out = torch.empty(B, Nq, H * D, dtype=value.dtype, device=value.device)
     if (value.dtype == torch.bfloat16 and value_layout == "bhsd" and mask_ptr is None and not value_ld
-            and (algo == "resident" or (algo == "auto" and _resident_pays(B, Nq, L)))):
+            and (algo == "resident" or (algo == "auto" and _resident_pays(B, Nq, L, host_levels(spatial_shapes, level_start_index)[0])))):
         hs, st_h = _host_level_arrays(spatial_shapes, level_start_index)
         st = lib.rdetr_msda_forward_fused_resident_bf16(
             value.data_ptr(), hs, st_h, sampling_offsets.data_ptr(), ld_off, attn_logits.data_ptr(), ld_lg,

@@ -262,3 +262,12 @@ def test_contiguous_copies_of_small_operands_stay_referenced():
     assert p != t.data_ptr() and len(ops._KEEP) == min(before + 1, ops._KEEP.maxlen)
     kept = ops._KEEP[-1]
     assert kept.data_ptr() == p and kept.is_contiguous() and torch.equal(kept, t[::2])
+
+
+def test_resident_kernel_policy():
+    """'auto' takes the resident-levels kernel only where it was measured faster: 4 levels, levels 2 + 3 resident, many queries."""
+    r50 = ((100, 168), (50, 84), (25, 42), (13, 21))
+    assert ops._resident_pays(4, 22323, 4, r50) and ops._resident_pays(1, 22323, 4, r50)
+    assert not ops._resident_pays(4, 900, 4, r50)                                      # decoder cross-attention: few queries
+    assert not ops._resident_pays(2, 204098, 5, ((300, 500), (150, 250), (75, 125), (38, 63), (19, 32)))
+    assert not ops._resident_pays(2, 46000, 4, ((150, 250), (75, 125), (38, 63), (19, 32)))   # levels 2 + 3 = 192 KB: only one would fit

@@ -154,3 +154,19 @@ def test_resident_full_size_properties(ops):
     d = ops.ms_deform_attn_forward(vh, *dev, value_layout="bhsd", algo="direct").float()
     assert ((o1.float() - d).abs() <= 2.0 ** -7 * d.abs() + 1e-3).all()
     assert torch.equal(ops.ms_deform_attn_forward(vh, *dev, value_layout="bhsd"), o1)           # auto
+
+
+def test_resident_kernel_in_a_captured_graph(ops):
+    """The kernel only enqueues on the current stream (its LDS attribute and the CU count are looked up in the warm-up): a HIP-graph
+    replay reproduces the eager launch bit for bit, also with new inputs copied into the captured buffers."""
+    from relation_detr_amd.graph import GraphedCall
+    value, shp, start, loc, attn, S, L = _encoder_inputs(R50, 1, 4.0, seed=3)
+    shp_d, start_d = shp.to(DEV), start.to(DEV)
+    vh, loc_d, attn_d = _head_major(value.to(DEV)), loc.to(DEV), attn.to(DEV)
+    fn = lambda v, lo, at: ops.ms_deform_attn_forward(v, shp_d, start_d, lo, at, value_layout="bhsd", algo="resident")
+    eager = fn(vh, loc_d, attn_d).clone()
+    run = GraphedCall(fn, [vh.clone(), loc_d.clone(), attn_d.clone()])
+    assert torch.equal(run(vh, loc_d, attn_d), eager)
+    value2, _, _, loc2, attn2, _, _ = _encoder_inputs(R50, 1, 6.0, seed=4)
+    vh2, loc2_d, attn2_d = _head_major(value2.to(DEV)), loc2.to(DEV), attn2.to(DEV)
+    assert torch.equal(run(vh2, loc2_d, attn2_d), fn(vh2, loc2_d, attn2_d))
